@@ -1,0 +1,271 @@
+/*
+ * fovpt.h -- C ABI of libfovpt, the MI355X (gfx950) foveated path-tracing launch.
+ *
+ * This is the drop-in boundary for ONE hot path of the reference renderer
+ * (bipul-mohanto/fovPathTracing_optixCodeLatest): the per-frame foveated launch
+ *   SampleRenderer::render()            PT_sv5_/SimplePathtracer.cpp:77-214
+ *     -> 3 x optixLaunch                PT_sv5_/SimplePathtracer.cpp:148-209
+ *       -> __raygen__renderFrame        PT_sv5_/deviceProgram.cu:392-617
+ *       -> __closesthit__radiance       PT_sv5_/deviceProgram.cu:619-732
+ *       -> miss / occlusion programs    PT_sv5_/deviceProgram.cu:253-300
+ * Everything the reference obtained from OptiX for that path (accel build,
+ * traversal, SBT, launch) lives behind these entry points.  Plain pointers and
+ * sizes only; no C++ or torch types.  Every function returns 0 on success and
+ * a negative FOVPT_E_* code on failure; fovpt_last_error() gives the text
+ * (the reference throws sutil::Exception, sutil/Exception.h:93-193 -- the C++
+ * shim in SimplePathtracer.h converts codes back into std::runtime_error).
+ *
+ * All structs below are bit-compatible with the reference's device-visible
+ * structs as built by nvcc (8-byte aligned int2/uint2/float2, 16-byte float4):
+ *   fovpt_material        == Material              PT_sv5_/Material.h:11-70      (104 B)
+ *   fovpt_probe           == Probe                 PT_sv5_/Probe.cuh:6-21        ( 64 B)
+ *   fovpt_launch_params   == LaunchParams          PT_sv5_/LaunchParams.h:49-91  (248 B)
+ */
+#ifndef FOVPT_H
+#define FOVPT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FOVPT_OK              0
+#define FOVPT_E_INVALID      -1  /* bad argument / inconsistent sizes            */
+#define FOVPT_E_DEVICE       -2  /* a HIP runtime call failed                     */
+#define FOVPT_E_NO_SCENE     -3  /* launch before fovpt_set_scene                 */
+#define FOVPT_E_NO_PROBE     -4  /* launch with a null probe                      */
+#define FOVPT_E_NO_FRAME     -5  /* launch with null frame buffers                */
+#define FOVPT_E_BVH_DEPTH    -6  /* built hierarchy deeper than the traversal stack */
+#define FOVPT_E_NOMEM        -7
+
+/* ---- POD vectors (layout of CUDA vector_types.h) --------------------------- */
+typedef struct { float x, y, z; } fovpt_float3;
+typedef struct { float x, y, z, w; } fovpt_float4;
+typedef struct { int32_t x, y; } fovpt_int2;
+typedef struct { uint32_t x, y; } fovpt_uint2;
+typedef struct { uint32_t x, y, z; } fovpt_uint3;
+
+/* ---- Material: PT_sv5_/Material.h:48-69 ------------------------------------ */
+#define FOVPT_MATERIAL_FLAG_SHADOW_CATCHER 1 /* Material.h:9 */
+typedef struct fovpt_material {
+    fovpt_float3 emission;      /*   0 */
+    fovpt_float3 color;         /*  12 */
+    fovpt_float3 absorption;    /*  24 */
+    float eta;                  /*  36 */
+    float metallic;             /*  40 */
+    float subsurface;           /*  44 */
+    float specular;             /*  48 */
+    float roughness;            /*  52 */
+    float specularTint;         /*  56 */
+    float anisotropic;          /*  60 */
+    float sheen;                /*  64 */
+    float sheenTint;            /*  68 */
+    float clearcoat;            /*  72 */
+    float clearcoatGloss;       /*  76 */
+    float transmission;         /*  80 */
+    float bump;                 /*  84 */
+    fovpt_float3 bumpTile;      /*  88 */
+    int32_t flags;              /* 100 */
+} fovpt_material;               /* 104 */
+
+/* ---- Probe: PT_sv5_/Probe.cuh:6-21 (device pointers) ----------------------- */
+typedef struct fovpt_probe {
+    int32_t width;              /*  0 */
+    int32_t height;             /*  4 */
+    fovpt_float4* data;         /*  8 */
+    fovpt_float3 offset;        /* 16 */
+    uint32_t _pad0;             /* 28 */
+    float* pdfValuesX;          /* 32 */
+    float* cdfValuesX;          /* 40 */
+    float* pdfValuesY;          /* 48 */
+    float* cdfValuesY;          /* 56 */
+} fovpt_probe;                  /* 64 */
+
+/* ---- LaunchParams: PT_sv5_/LaunchParams.h:49-91 ----------------------------- */
+typedef struct fovpt_launch_params {
+    struct {
+        fovpt_float4* accum_buffer;  /*   0  float4 per pixel, device            */
+        uint32_t* frame_buffer;      /*   8  rgba8 per pixel (uchar4), device    */
+        fovpt_float4* color_buffer;  /*  16  dead in sv5                         */
+        fovpt_float4* normal_buffer; /*  24  dead in sv5                         */
+        fovpt_float4* albedo_buffer; /*  32  dead in sv5                         */
+        fovpt_int2 size;             /*  40                                      */
+        uint32_t subframe_index;     /*  48                                      */
+        fovpt_uint3 factor;          /*  52                                      */
+        int32_t fillSize;            /*  64                                      */
+        uint32_t _pad0;              /*  68                                      */
+        fovpt_uint2 c;               /*  72  gaze centre, pixels                 */
+        float r_inner;               /*  80                                      */
+        float r_outer;               /*  84                                      */
+        fovpt_uint2 offset;          /*  88                                      */
+        uint32_t redraw;             /*  96                                      */
+        uint32_t _pad1;              /* 100                                      */
+    } frame;
+    struct {
+        fovpt_float3 eye;            /* 104 */
+        fovpt_float3 U;              /* 116 */
+        fovpt_float3 V;              /* 128 */
+        fovpt_float3 W;              /* 140 */
+    } camera;
+    uint32_t samples_per_launch;     /* 152 */
+    uint32_t _pad2;                  /* 156 */
+    uint64_t traversable;            /* 160  scene handle from fovpt_set_scene   */
+    fovpt_probe probe;               /* 168 */
+    fovpt_int2 viewportSize;         /* 232  dead in sv5                         */
+    float white;                     /* 240  dead in sv5                         */
+    uint32_t _pad3;                  /* 244 */
+} fovpt_launch_params;               /* 248 */
+
+/* ---- scene upload: replaces buildAccel + createTextures + buildSBT ----------
+ * (PT_sv5_/SimplePathtracer.cpp:602-746, 748-799, 534-599).  Host pointers;
+ * everything is copied before the call returns.                                */
+typedef struct fovpt_mesh_desc {
+    const float* vertex;        /* xyz triples, TriangleMesh::vertex  (Model.h:12) */
+    const float* normal;        /* xyz triples or NULL; the path never reads them
+                                   (deviceProgram.cu:632-634 uses the face normal) */
+    const float* texcoord;      /* uv pairs per vertex or NULL        (Model.h:14) */
+    const uint32_t* index;      /* 3 per triangle                     (Model.h:15) */
+    uint32_t num_vertices;
+    uint32_t num_triangles;
+    int32_t texture_id;         /* TriangleMesh::diffuseTextureID; <0 = untextured */
+    fovpt_material material;
+} fovpt_mesh_desc;
+
+typedef struct fovpt_texture_desc {
+    const uint32_t* pixel;      /* RGBA8, row-major, Texture::pixel (Model.h:27)   */
+    int32_t width, height;      /* Texture::resolution                             */
+} fovpt_texture_desc;
+
+/* ---- run-time configuration (the reference's compile-time #defines) ---------
+ * Defaults reproduce PT_sv5_ as shipped: FOV_ON, radii 74/241
+ * (SimplePathtracer.cpp:20-23), spp 8/16/32 (:142,170,193), uniform spp 4 (:95),
+ * depth cap 4 (deviceProgram.cu:515), accumulate off (:565-581).               */
+typedef struct fovpt_config {
+    int32_t uniform;            /* 1 = FOV_OFF branch (SimplePathtracer.cpp:85-131) */
+    int32_t r_inner;            /* inner_radius                                    */
+    int32_t r_outer;            /* outer_radius                                    */
+    int32_t spp_periphery;      /* samples_per_launch of pass P                    */
+    int32_t spp_middle;         /* ... pass M                                      */
+    int32_t spp_fovea;          /* ... pass F                                      */
+    int32_t spp_uniform;        /* ... FOV_OFF                                     */
+    int32_t max_depth;          /* depth cap, deviceProgram.cu:515                 */
+    int32_t accumulate;         /* 1 = PT_sv4_vmv2 clamp(0,10)+running mean
+                                   (OtherProjects_02_latest/PT_sv4_vmv2/deviceProgram.cu:545-553) */
+    int32_t rank;               /* multi-GPU tile shard: this handle renders the   */
+    int32_t world;              /* launch-index tiles t with owner(t) == rank      */
+    int32_t tile_w, tile_h;     /* launch-index tile, default 8 x 4
+                                   (sutil/WorkDistribution.h:47-84 scheme)         */
+    int32_t profile;            /* 1 = time each kernel with hipEvents             */
+    int32_t sort_rays;          /* reserved                                        */
+    int32_t reserved[1];
+} fovpt_config;
+
+typedef struct fovpt_stats {
+    uint64_t radiance_rays;     /* closest-hit rays traced since last reset        */
+    uint64_t shadow_rays;       /* occlusion rays traced                           */
+    uint64_t paths;             /* camera paths started                            */
+    uint64_t frames;            /* fovpt_render / fovpt_launch calls               */
+    /* per-kernel device time, only filled when config.profile = 1                */
+    double ms_generate, ms_trace, ms_shade, ms_shadow, ms_resolve;
+    uint64_t n_trace_launches;  /* closest-hit kernel launches behind ms_trace     */
+    uint64_t n_shadow_launches;
+    /* scene facts */
+    uint64_t num_triangles, num_bvh_nodes, bvh_max_depth, bvh_bytes, tri_bytes;
+    double ms_bvh_build;
+} fovpt_stats;
+
+typedef struct fovpt_frame_ptrs {   /* what resize() allocates, SimplePathtracer.cpp:242-260 */
+    uint32_t* frame_buffer;
+    fovpt_float4* accum_buffer;
+    fovpt_float4* color_buffer;
+    fovpt_float4* normal_buffer;
+    fovpt_float4* albedo_buffer;
+} fovpt_frame_ptrs;
+
+typedef struct fovpt_ctx fovpt_ctx;
+
+/* SampleRenderer ctor minus the scene: initOptix/createContext (SimplePathtracer.cpp:310-340). */
+int fovpt_create(fovpt_ctx** out, int device);
+void fovpt_destroy(fovpt_ctx* ctx);
+const char* fovpt_last_error(const fovpt_ctx* ctx);  /* ctx may be NULL: last create error */
+
+/* buildAccel + createTextures + buildSBT.  *traversable_out is what the reference
+ * stores in launchParams.traversable (SimplePathtracer.cpp:61).                   */
+int fovpt_set_scene(fovpt_ctx* ctx, const fovpt_mesh_desc* meshes, int num_meshes,
+                    const fovpt_texture_desc* textures, int num_textures,
+                    uint64_t* traversable_out);
+
+/* CUDAProbeData::createBuffer (Probe.h:102-124): uploads the 5 arrays, fills *probe_out
+ * with device pointers exactly as setProbe does (SimplePathtracer.cpp:292-308).   */
+int fovpt_set_probe(fovpt_ctx* ctx, int width, int height, const fovpt_float4* data,
+                    const float* pdfValuesX, const float* cdfValuesX,
+                    const float* pdfValuesY, const float* cdfValuesY,
+                    const fovpt_float3* offset, fovpt_probe* probe_out);
+
+/* SampleRenderer::resize (SimplePathtracer.cpp:228-274): (re)allocates the five
+ * full-frame buffers.  No-op returning FOVPT_OK with *out untouched when w or h is 0. */
+int fovpt_resize(fovpt_ctx* ctx, int width, int height, fovpt_frame_ptrs* out);
+
+int fovpt_get_config(const fovpt_ctx* ctx, fovpt_config* out);
+int fovpt_set_config(fovpt_ctx* ctx, const fovpt_config* cfg);
+
+/* One optixLaunch of the raygen program over a width x height grid with the given
+ * parameters (SimplePathtracer.cpp:148-157).  Asynchronous on fovpt_stream().     */
+int fovpt_launch(fovpt_ctx* ctx, const fovpt_launch_params* lp, uint32_t width, uint32_t height);
+
+/* SampleRenderer::render() (SimplePathtracer.cpp:77-214): fills in the per-pass
+ * fields of *lp exactly as the reference mutates its public launchParams (factor,
+ * fillSize, radii, offset, redraw, samples_per_launch; ++subframe_index), and runs
+ * the three passes (or the FOV_OFF pass) as ONE fused wavefront job.  Silently
+ * returns FOVPT_OK when lp->frame.size.x == 0 (:81-82).  Asynchronous.            */
+int fovpt_render(fovpt_ctx* ctx, fovpt_launch_params* lp);
+
+/* CUDA_SYNC_CHECK() (SimplePathtracer.cpp:212). */
+int fovpt_synchronize(fovpt_ctx* ctx);
+
+/* CUDABuffer::download (CUDABuffer.h:82-88): device -> host copy of n_bytes.      */
+int fovpt_download(fovpt_ctx* ctx, const void* device_src, void* host_dst, size_t n_bytes);
+
+int fovpt_get_stats(fovpt_ctx* ctx, fovpt_stats* out);   /* synchronises first */
+int fovpt_reset_stats(fovpt_ctx* ctx);
+void* fovpt_stream(fovpt_ctx* ctx);                      /* hipStream_t; SampleRenderer::stream */
+
+/* ---- host-side helpers that the reference runs on the CPU too ---------------- */
+/* ProbeData::BuildCDF (Probe.h:29-77): sequential fp32 accumulation, order preserved. */
+int fovpt_probe_build_cdf(int width, int height, const fovpt_float4* data,
+                          float* pdfValuesX, float* cdfValuesX,
+                          float* pdfValuesY, float* cdfValuesY);
+/* sutil::Camera::UVWFrame (sutil/Camera.cpp:32-44). */
+int fovpt_camera_uvw(const fovpt_float3* eye, const fovpt_float3* lookat, const fovpt_float3* up,
+                     float fovY_degrees, float aspect,
+                     fovpt_float3* U, fovpt_float3* V, fovpt_float3* W);
+
+/* ---- device self-test hook (tests only): evaluates one scalar function on the GPU
+ * for n inputs; op codes FOVPT_OP_*.  a,b host arrays (b may be NULL), out host.  */
+#define FOVPT_OP_SIN    1
+#define FOVPT_OP_COS    2
+#define FOVPT_OP_ACOS   3
+#define FOVPT_OP_ATAN2  4
+#define FOVPT_OP_LOG    5
+#define FOVPT_OP_POW    6
+#define FOVPT_OP_SQRT   7
+#define FOVPT_OP_DIV    8
+#define FOVPT_OP_RSQRTD 9   /* (float)(1.0 / (double)sqrtf(a)), maths.h:98 */
+int fovpt_debug_math(fovpt_ctx* ctx, int op, const float* a, const float* b, float* out, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+
+#ifdef __cplusplus
+static_assert(sizeof(fovpt_material) == 104, "Material ABI");
+static_assert(sizeof(fovpt_probe) == 64, "Probe ABI");
+static_assert(sizeof(fovpt_launch_params) == 248, "LaunchParams ABI");
+static_assert(offsetof(fovpt_launch_params, camera) == 104, "LaunchParams ABI");
+static_assert(offsetof(fovpt_launch_params, traversable) == 160, "LaunchParams ABI");
+static_assert(offsetof(fovpt_launch_params, probe) == 168, "LaunchParams ABI");
+#endif
+
+#endif /* FOVPT_H */
