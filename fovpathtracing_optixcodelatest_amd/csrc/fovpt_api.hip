@@ -1,0 +1,648 @@
+// fovpt_api.hip -- host side of libfovpt: the C ABI of include/fovpt.h over HIP.
+//
+// One context = one device = one stream, like the reference's SampleRenderer
+// (PT_sv5_/SimplePathtracer.cpp:331-340).  Calls on a context are not thread-safe.
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fovpt_device.h"
+
+namespace {
+
+std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= bytes) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr; bytes = 0;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+struct EventPair { hipEvent_t a, b; int kind; };   // kind: 0 gen, 1 trace, 2 shade, 3 shadow, 4 resolve
+
+}  // namespace
+
+struct fovpt_ctx {
+    int device = 0;
+    int num_cus = 256;
+    hipStream_t stream = nullptr;
+    std::string err;
+    fovpt_config cfg;
+    // scene
+    bool has_scene = false;
+    uint64_t scene_id = 0;
+    BvhNode* nodes = nullptr;
+    TriRec* tris = nullptr;
+    DevBuf tri_tc, meshes, textures;
+    std::vector<void*> tex_pixels;
+    uint32_t num_tris = 0, any_catcher = 0;
+    // probe
+    DevBuf pr_data, pr_pdfx, pr_cdfx, pr_pdfy, pr_cdfy;
+    // frame buffers (resize)
+    DevBuf fb_frame, fb_accum, fb_color, fb_normal, fb_albedo;
+    // wavefront state
+    DevBuf s_ray_o, s_ray_d, s_thr, s_rng, s_hit, s_direct, s_indirect, s_alpha, s_backplate;
+    DevBuf q_a, q_b, sq_o, sq_d, sq_vis, sq_occ, counters, spill;
+    int grid = 2048;
+    // stats
+    fovpt_stats stats;
+    std::vector<EventPair> pending;
+    std::vector<hipEvent_t> free_events;
+};
+
+namespace {
+
+int fail(fovpt_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail((c), FOVPT_E_DEVICE, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
+
+fovpt_config default_config()
+{
+    fovpt_config c;
+    memset(&c, 0, sizeof(c));
+    c.uniform = 0;
+    c.r_inner = 74; c.r_outer = 241;                    // SimplePathtracer.cpp:20-21
+    c.spp_periphery = 8; c.spp_middle = 16; c.spp_fovea = 32;   // :142,170,193
+    c.spp_uniform = 4;                                  // :95
+    c.max_depth = 4;                                    // deviceProgram.cu:515
+    c.accumulate = 0;
+    c.rank = 0; c.world = 1; c.tile_w = 8; c.tile_h = 4;
+    return c;
+}
+
+hipEvent_t get_event(fovpt_ctx* c)
+{
+    if (!c->free_events.empty()) { hipEvent_t e = c->free_events.back(); c->free_events.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+struct Timed {
+    fovpt_ctx* c; int kind; hipEvent_t a = nullptr, b = nullptr;
+    Timed(fovpt_ctx* c_, int k) : c(c_), kind(k)
+    {
+        if (c->cfg.profile) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); }
+    }
+    ~Timed()
+    {
+        if (c->cfg.profile) { (void)hipEventRecord(b, c->stream); EventPair p = {a, b, kind}; c->pending.push_back(p); }
+    }
+};
+
+void drain_events(fovpt_ctx* c)
+{
+    for (auto& p : c->pending) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            switch (p.kind) {
+            case 0: c->stats.ms_generate += ms; break;
+            case 1: c->stats.ms_trace += ms; c->stats.n_trace_launches++; break;
+            case 2: c->stats.ms_shade += ms; break;
+            case 3: c->stats.ms_shadow += ms; c->stats.n_shadow_launches++; break;
+            case 4: c->stats.ms_resolve += ms; break;
+            }
+        }
+        c->free_events.push_back(p.a); c->free_events.push_back(p.b);
+    }
+    c->pending.clear();
+}
+
+void free_scene(fovpt_ctx* c)
+{
+    if (c->nodes) (void)hipFree(c->nodes);
+    if (c->tris) (void)hipFree(c->tris);
+    c->nodes = nullptr; c->tris = nullptr;
+    for (void* p : c->tex_pixels) (void)hipFree(p);
+    c->tex_pixels.clear();
+    c->has_scene = false;
+}
+
+int ensure_state(fovpt_ctx* c, size_t slots, size_t launches)
+{
+    const size_t v = 16;
+    HIPCHK(c, c->s_ray_o.reserve(slots * v)); HIPCHK(c, c->s_ray_d.reserve(slots * v));
+    HIPCHK(c, c->s_thr.reserve(slots * v)); HIPCHK(c, c->s_rng.reserve(slots * v));
+    HIPCHK(c, c->s_hit.reserve(slots * v)); HIPCHK(c, c->s_direct.reserve(slots * v));
+    HIPCHK(c, c->s_indirect.reserve(slots * v)); HIPCHK(c, c->s_alpha.reserve(slots * v));
+    HIPCHK(c, c->s_backplate.reserve(launches * v));
+    HIPCHK(c, c->q_a.reserve(slots * 4)); HIPCHK(c, c->q_b.reserve(slots * 4));
+    HIPCHK(c, c->sq_o.reserve(slots * v)); HIPCHK(c, c->sq_d.reserve(slots * v));
+    HIPCHK(c, c->sq_vis.reserve(slots * v)); HIPCHK(c, c->sq_occ.reserve(slots * v));
+    if (!c->counters.p) {
+        HIPCHK(c, c->counters.reserve(sizeof(Counters)));
+        HIPCHK(c, hipMemsetAsync(c->counters.p, 0, sizeof(Counters), c->stream));
+    }
+    HIPCHK(c, c->spill.reserve((size_t)c->grid * FOVPT_BLOCK * FOVPT_STACK_SPILL * sizeof(int)));
+    return FOVPT_OK;
+}
+
+// The engine: all passes of one frame as one wavefront job.
+int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_in, int npass)
+{
+    if (!c->has_scene || lp->traversable != c->scene_id) return fail(c, FOVPT_E_NO_SCENE, "launch without a scene (traversable %llu, current %llu)",
+                                                                     (unsigned long long)lp->traversable, (unsigned long long)c->scene_id);
+    if (!lp->probe.data || !lp->probe.cdfValuesX || !lp->probe.cdfValuesY || !lp->probe.pdfValuesX || !lp->probe.pdfValuesY
+        || lp->probe.width <= 0 || lp->probe.height <= 0)
+        return fail(c, FOVPT_E_NO_PROBE, "launch with an incomplete probe");
+    if (!lp->frame.accum_buffer || !lp->frame.frame_buffer) return fail(c, FOVPT_E_NO_FRAME, "launch with null frame buffers");
+    if (lp->frame.size.x <= 0 || lp->frame.size.y <= 0) return fail(c, FOVPT_E_INVALID, "bad frame size");
+    if (c->cfg.max_depth < 1 || c->cfg.max_depth > 32) return fail(c, FOVPT_E_INVALID, "max_depth out of range");
+
+    FrameDev fd;
+    memset(&fd, 0, sizeof(fd));
+    uint64_t slots = 0, launches = 0;
+    for (int p = 0; p < npass; p++) {
+        PassDev P = passes_in[p];
+        if (P.spp == 0) return fail(c, FOVPT_E_INVALID, "samples_per_launch must be >= 1 (do{}while(--i), deviceProgram.cu:448,539)");
+        P.slot_base = (uint32_t)slots; P.launch_base = (uint32_t)launches;
+        slots += (uint64_t)P.gw * P.gh * P.spp;
+        launches += (uint64_t)P.gw * P.gh;
+        fd.pass[p] = P;
+    }
+    if (slots >= (1ull << 31)) return fail(c, FOVPT_E_INVALID, "launch too large: %llu sample slots", (unsigned long long)slots);
+    fd.npass = npass;
+    fd.w = lp->frame.size.x; fd.h = lp->frame.size.y;
+    fd.cx = lp->frame.c.x; fd.cy = lp->frame.c.y;
+    const fovpt_float3* cam[4] = {&lp->camera.eye, &lp->camera.U, &lp->camera.V, &lp->camera.W};
+    float* dst[4] = {fd.eye, fd.U, fd.V, fd.W};
+    for (int k = 0; k < 4; k++) { dst[k][0] = cam[k]->x; dst[k][1] = cam[k]->y; dst[k][2] = cam[k]->z; }
+    fd.probe = lp->probe;
+    fd.accum = lp->frame.accum_buffer;
+    fd.frame = lp->frame.frame_buffer;
+    fd.total_slots = (uint32_t)slots;
+    fd.max_depth = c->cfg.max_depth;
+    fd.accumulate = c->cfg.accumulate;
+    fd.rank = c->cfg.rank; fd.world = c->cfg.world < 1 ? 1 : c->cfg.world;
+    fd.tile_w = c->cfg.tile_w > 0 ? c->cfg.tile_w : 8; fd.tile_h = c->cfg.tile_h > 0 ? c->cfg.tile_h : 4;
+
+    c->stats.frames++;
+    if (slots == 0) return FOVPT_OK;
+    int rc = ensure_state(c, (size_t)slots, (size_t)launches);
+    if (rc) return rc;
+
+    PathState ps;
+    ps.ray_o = (float4*)c->s_ray_o.p; ps.ray_d = (float4*)c->s_ray_d.p; ps.thr = (float4*)c->s_thr.p;
+    ps.rng = (uint4*)c->s_rng.p; ps.hit = (float4*)c->s_hit.p; ps.direct = (float4*)c->s_direct.p;
+    ps.indirect = (float4*)c->s_indirect.p; ps.alpha = (float4*)c->s_alpha.p; ps.backplate = (float4*)c->s_backplate.p;
+    ShadowQueue sq;
+    sq.o = (float4*)c->sq_o.p; sq.d = (float4*)c->sq_d.p; sq.val_vis = (float4*)c->sq_vis.p; sq.val_occ = (float4*)c->sq_occ.p;
+    SceneView sc;
+    sc.nodes = c->nodes; sc.tris = c->tris; sc.tri_tc = (const float2*)c->tri_tc.p;
+    sc.meshes = (const MeshDev*)c->meshes.p; sc.textures = (const TexDev*)c->textures.p;
+    sc.num_tris = c->num_tris; sc.any_catcher = c->any_catcher;
+    Counters* cnt = (Counters*)c->counters.p;
+    uint32_t* qa = (uint32_t*)c->q_a.p;
+    uint32_t* qb = (uint32_t*)c->q_b.p;
+    hipStream_t st = c->stream;
+
+    HIPCHK(c, hipMemsetAsync(cnt, 0, offsetof(Counters, stat_radiance), st));
+    const int grid = c->grid;
+    { Timed t(c, 0); fovpt_launch_generate(st, fd, ps, qa, cnt, (uint32_t)slots, grid); }
+    // iterations: depth 0 .. max_depth-1, plus the reference's discarded segment and shadow-catcher
+    // pass-throughs (which do not advance depth) when the scene holds a catcher
+    int iters = c->cfg.max_depth + (c->any_catcher ? 1 + 24 : 0);
+    if (iters > FOVPT_MAX_ITERS) iters = FOVPT_MAX_ITERS;
+    for (int it = 0; it < iters; it++) {
+        { Timed t(c, 1); fovpt_launch_trace(st, sc, ps, qa, cnt, it, (int*)c->spill.p, grid); }
+        { Timed t(c, 2); fovpt_launch_shade(st, fd, sc, ps, qa, qb, sq, cnt, it, grid); }
+        { Timed t(c, 3); fovpt_launch_shadow(st, sc, ps, sq, cnt, it, (int*)c->spill.p, grid); }
+        uint32_t* tmp = qa; qa = qb; qb = tmp;
+    }
+    { Timed t(c, 4); fovpt_launch_resolve(st, fd, ps); }
+    HIPCHK(c, hipGetLastError());
+    return FOVPT_OK;
+}
+
+PassDev pass_from_lp(const fovpt_launch_params* lp, uint32_t gw, uint32_t gh)
+{
+    PassDev P;
+    memset(&P, 0, sizeof(P));
+    P.gw = gw; P.gh = gh;
+    P.fx = lp->frame.factor.x; P.fy = lp->frame.factor.y; P.fz = lp->frame.factor.z;
+    P.fill = lp->frame.fillSize;
+    P.offx = lp->frame.offset.x; P.offy = lp->frame.offset.y;
+    P.r_inner = lp->frame.r_inner; P.r_outer = lp->frame.r_outer;
+    P.spp = lp->samples_per_launch;
+    P.subframe = lp->frame.subframe_index;
+    P.redraw = lp->frame.redraw;
+    return P;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fovpt_create(fovpt_ctx** out, int device)
+{
+    if (!out) return fail(nullptr, FOVPT_E_INVALID, "null out pointer");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0) return fail(nullptr, FOVPT_E_DEVICE, "no HIP device found (%s)", hipGetErrorString(e));   // initOptix :317-321
+    if (device < 0 || device >= n) return fail(nullptr, FOVPT_E_INVALID, "device %d out of range (%d devices)", device, n);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, FOVPT_E_DEVICE, "hipSetDevice: %s", hipGetErrorString(e));
+    fovpt_ctx* c = new fovpt_ctx;
+    c->device = device;
+    c->cfg = default_config();
+    memset(&c->stats, 0, sizeof(c->stats));
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
+    c->grid = c->num_cus * 8;                 // 8 blocks of 256 = 32 waves per CU, grid-stride over the queues
+    e = hipStreamCreate(&c->stream);
+    if (e != hipSuccess) { delete c; return fail(nullptr, FOVPT_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    *out = c;
+    return FOVPT_OK;
+}
+
+void fovpt_destroy(fovpt_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    drain_events(c);
+    for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
+    free_scene(c);
+    DevBuf* bufs[] = {&c->tri_tc, &c->meshes, &c->textures, &c->pr_data, &c->pr_pdfx, &c->pr_cdfx, &c->pr_pdfy, &c->pr_cdfy,
+                      &c->fb_frame, &c->fb_accum, &c->fb_color, &c->fb_normal, &c->fb_albedo,
+                      &c->s_ray_o, &c->s_ray_d, &c->s_thr, &c->s_rng, &c->s_hit, &c->s_direct, &c->s_indirect, &c->s_alpha, &c->s_backplate,
+                      &c->q_a, &c->q_b, &c->sq_o, &c->sq_d, &c->sq_vis, &c->sq_occ, &c->counters, &c->spill};
+    for (DevBuf* b : bufs) b->release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* fovpt_last_error(const fovpt_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int fovpt_set_scene(fovpt_ctx* c, const fovpt_mesh_desc* meshes, int num_meshes,
+                    const fovpt_texture_desc* textures, int num_textures, uint64_t* traversable_out)
+{
+    if (!c) return FOVPT_E_INVALID;
+    if (!meshes || num_meshes <= 0) return fail(c, FOVPT_E_INVALID, "scene needs at least one mesh");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_scene(c);
+    uint64_t ntri = 0;
+    bool any_tc = false;
+    for (int m = 0; m < num_meshes; m++) {
+        const fovpt_mesh_desc& D = meshes[m];
+        if (!D.vertex || !D.index) return fail(c, FOVPT_E_INVALID, "mesh %d has null vertex/index", m);
+        ntri += D.num_triangles;
+        if (D.texcoord && D.texture_id >= 0) any_tc = true;
+        if (D.texture_id >= num_textures) return fail(c, FOVPT_E_INVALID, "mesh %d references texture %d of %d (SimplePathtracer.cpp:581-583 would index out of range)", m, D.texture_id, num_textures);
+    }
+    if (ntri == 0) return fail(c, FOVPT_E_INVALID, "scene has no triangles");
+    if (ntri >= (1ull << 28)) return fail(c, FOVPT_E_INVALID, "too many triangles");
+    // flatten on the host: 9 floats per triangle in global primitive order (mesh order, then index order)
+    std::vector<float> flat((size_t)ntri * 9);
+    std::vector<uint32_t> mesh_of((size_t)ntri);
+    std::vector<float> tc(any_tc ? (size_t)ntri * 6 : 0, 0.0f);
+    std::vector<MeshDev> md((size_t)num_meshes);
+    c->any_catcher = 0;
+    size_t t = 0;
+    for (int m = 0; m < num_meshes; m++) {
+        const fovpt_mesh_desc& D = meshes[m];
+        md[m].material = D.material;
+        md[m].texture_id = D.texture_id >= 0 ? D.texture_id : -1;
+        md[m].has_texcoord = D.texcoord ? 1 : 0;
+        if (D.material.flags & FOVPT_MATERIAL_FLAG_SHADOW_CATCHER) c->any_catcher = 1;
+        for (uint32_t k = 0; k < D.num_triangles; k++, t++) {
+            for (int v = 0; v < 3; v++) {
+                const uint32_t idx = D.index[3 * (size_t)k + v];
+                if (idx >= D.num_vertices) return fail(c, FOVPT_E_INVALID, "mesh %d triangle %u indexes vertex %u of %u", m, k, idx, D.num_vertices);
+                flat[t * 9 + v * 3 + 0] = D.vertex[3 * (size_t)idx + 0];
+                flat[t * 9 + v * 3 + 1] = D.vertex[3 * (size_t)idx + 1];
+                flat[t * 9 + v * 3 + 2] = D.vertex[3 * (size_t)idx + 2];
+                if (any_tc && D.texcoord) { tc[t * 6 + v * 2] = D.texcoord[2 * (size_t)idx]; tc[t * 6 + v * 2 + 1] = D.texcoord[2 * (size_t)idx + 1]; }
+            }
+            mesh_of[t] = (uint32_t)m;
+        }
+    }
+    float* d_flat = nullptr; uint32_t* d_mesh_of = nullptr;
+    HIPCHK(c, hipMalloc(&d_flat, flat.size() * 4));
+    HIPCHK(c, hipMalloc(&d_mesh_of, mesh_of.size() * 4));
+    HIPCHK(c, hipMemcpy(d_flat, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(d_mesh_of, mesh_of.data(), mesh_of.size() * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, c->meshes.reserve(md.size() * sizeof(MeshDev)));
+    HIPCHK(c, hipMemcpy(c->meshes.p, md.data(), md.size() * sizeof(MeshDev), hipMemcpyHostToDevice));
+    if (any_tc) {
+        HIPCHK(c, c->tri_tc.reserve(tc.size() * 4));
+        HIPCHK(c, hipMemcpy(c->tri_tc.p, tc.data(), tc.size() * 4, hipMemcpyHostToDevice));
+    }
+    // textures: createTextures :748-799 (RGBA8, wrap, bilinear, normalized float)
+    std::vector<TexDev> td((size_t)(num_textures > 0 ? num_textures : 1));
+    for (int k = 0; k < num_textures; k++) {
+        const fovpt_texture_desc& X = textures[k];
+        if (!X.pixel || X.width <= 0 || X.height <= 0) return fail(c, FOVPT_E_INVALID, "texture %d is empty", k);
+        void* px = nullptr;
+        const size_t nb = (size_t)X.width * X.height * 4;
+        HIPCHK(c, hipMalloc(&px, nb));
+        c->tex_pixels.push_back(px);
+        HIPCHK(c, hipMemcpy(px, X.pixel, nb, hipMemcpyHostToDevice));
+        td[k].px = (const uint32_t*)px; td[k].w = X.width; td[k].h = X.height;
+    }
+    HIPCHK(c, c->textures.reserve(td.size() * sizeof(TexDev)));
+    HIPCHK(c, hipMemcpy(c->textures.p, td.data(), td.size() * sizeof(TexDev), hipMemcpyHostToDevice));
+
+    hipEvent_t e0, e1;
+    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    BvhBuildResult br;
+    memset(&br, 0, sizeof(br));
+    char errbuf[256];
+    hipError_t be = fovpt_build_lbvh(c->stream, d_flat, d_mesh_of, (uint32_t)ntri, &br, errbuf, sizeof(errbuf));
+    (void)hipEventRecord(e1, c->stream);
+    (void)hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(d_flat); (void)hipFree(d_mesh_of);
+    if (be != hipSuccess) return fail(c, FOVPT_E_DEVICE, "LBVH build: %s", errbuf);
+    if (br.max_depth > FOVPT_STACK_LDS + FOVPT_STACK_SPILL) {
+        (void)hipFree(br.nodes); (void)hipFree(br.tris);
+        return fail(c, FOVPT_E_BVH_DEPTH, "hierarchy depth %u exceeds the traversal stack (%d)", br.max_depth, FOVPT_STACK_LDS + FOVPT_STACK_SPILL);
+    }
+    c->nodes = br.nodes; c->tris = br.tris;
+    c->num_tris = (uint32_t)ntri;
+    c->has_scene = true;
+    c->scene_id = (c->scene_id & 0xffffffffull) + 1;
+    c->scene_id |= 0x464f565000000000ull;          // 'FOVP' tag so a stale/foreign handle is recognisable
+    c->stats.num_triangles = ntri; c->stats.num_bvh_nodes = br.num_nodes; c->stats.bvh_max_depth = br.max_depth;
+    c->stats.bvh_bytes = br.node_bytes; c->stats.tri_bytes = br.tri_bytes; c->stats.ms_bvh_build = ms;
+    if (traversable_out) *traversable_out = c->scene_id;
+    return FOVPT_OK;
+}
+
+int fovpt_set_probe(fovpt_ctx* c, int width, int height, const fovpt_float4* data,
+                    const float* pdfX, const float* cdfX, const float* pdfY, const float* cdfY,
+                    const fovpt_float3* offset, fovpt_probe* out)
+{
+    if (!c) return FOVPT_E_INVALID;
+    if (!data || !pdfX || !cdfX || !pdfY || !cdfY || width <= 0 || height <= 0 || !out)
+        return fail(c, FOVPT_E_INVALID, "Probe Data is not valid");                         // Probe.h:104-105
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)width * height;
+    HIPCHK(c, c->pr_pdfx.reserve(n * 4)); HIPCHK(c, c->pr_cdfx.reserve(n * 4));
+    HIPCHK(c, c->pr_pdfy.reserve((size_t)height * 4)); HIPCHK(c, c->pr_cdfy.reserve((size_t)height * 4));
+    HIPCHK(c, c->pr_data.reserve(n * 16));
+    HIPCHK(c, hipMemcpy(c->pr_pdfx.p, pdfX, n * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->pr_cdfx.p, cdfX, n * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->pr_pdfy.p, pdfY, (size_t)height * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->pr_cdfy.p, cdfY, (size_t)height * 4, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->pr_data.p, data, n * 16, hipMemcpyHostToDevice));
+    memset(out, 0, sizeof(*out));
+    out->width = width; out->height = height;
+    out->data = (fovpt_float4*)c->pr_data.p;
+    out->pdfValuesX = (float*)c->pr_pdfx.p; out->cdfValuesX = (float*)c->pr_cdfx.p;
+    out->pdfValuesY = (float*)c->pr_pdfy.p; out->cdfValuesY = (float*)c->pr_cdfy.p;
+    if (offset) out->offset = *offset;
+    return FOVPT_OK;
+}
+
+int fovpt_resize(fovpt_ctx* c, int width, int height, fovpt_frame_ptrs* out)
+{
+    if (!c) return FOVPT_E_INVALID;
+    if (width == 0 || height == 0) return FOVPT_OK;                                          // :231
+    if (width < 0 || height < 0 || !out) return fail(c, FOVPT_E_INVALID, "bad resize arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const size_t n = (size_t)width * height;
+    HIPCHK(c, c->fb_frame.reserve(n * 4)); HIPCHK(c, c->fb_accum.reserve(n * 16));
+    HIPCHK(c, c->fb_color.reserve(n * 16)); HIPCHK(c, c->fb_normal.reserve(n * 16)); HIPCHK(c, c->fb_albedo.reserve(n * 16));
+    HIPCHK(c, hipMemset(c->fb_frame.p, 0, n * 4));
+    HIPCHK(c, hipMemset(c->fb_accum.p, 0, n * 16));
+    out->frame_buffer = (uint32_t*)c->fb_frame.p; out->accum_buffer = (fovpt_float4*)c->fb_accum.p;
+    out->color_buffer = (fovpt_float4*)c->fb_color.p; out->normal_buffer = (fovpt_float4*)c->fb_normal.p;
+    out->albedo_buffer = (fovpt_float4*)c->fb_albedo.p;
+    return FOVPT_OK;
+}
+
+int fovpt_get_config(const fovpt_ctx* c, fovpt_config* out)
+{
+    if (!c || !out) return FOVPT_E_INVALID;
+    *out = c->cfg;
+    return FOVPT_OK;
+}
+
+int fovpt_set_config(fovpt_ctx* c, const fovpt_config* cfg)
+{
+    if (!c || !cfg) return FOVPT_E_INVALID;
+    if (cfg->max_depth < 1 || cfg->max_depth > 32) return fail(c, FOVPT_E_INVALID, "max_depth must be in [1,32]");
+    if (cfg->world < 1 || cfg->rank < 0 || cfg->rank >= cfg->world) return fail(c, FOVPT_E_INVALID, "bad rank/world %d/%d", cfg->rank, cfg->world);
+    if (cfg->spp_periphery < 1 || cfg->spp_middle < 1 || cfg->spp_fovea < 1 || cfg->spp_uniform < 1) return fail(c, FOVPT_E_INVALID, "spp must be >= 1");
+    if (cfg->r_inner < 0 || cfg->r_outer < cfg->r_inner) return fail(c, FOVPT_E_INVALID, "bad radii");
+    c->cfg = *cfg;
+    return FOVPT_OK;
+}
+
+int fovpt_launch(fovpt_ctx* c, const fovpt_launch_params* lp, uint32_t width, uint32_t height)
+{
+    if (!c || !lp) return FOVPT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    PassDev P = pass_from_lp(lp, width, height);
+    return run_passes(c, lp, &P, 1);
+}
+
+int fovpt_render(fovpt_ctx* c, fovpt_launch_params* lp)
+{
+    if (!c || !lp) return FOVPT_E_INVALID;
+    if (lp->frame.size.x == 0) return FOVPT_OK;                                              // :81-82
+    HIPCHK(c, hipSetDevice(c->device));
+    fovpt_launch_params& L = *lp;
+    const fovpt_config& cfg = c->cfg;
+    PassDev P[3];
+    int rc;
+    if (cfg.uniform) {                                                                       // FOV_OFF :85-131
+        L.frame.subframe_index = 0;
+        L.frame.factor.x = L.frame.factor.y = L.frame.factor.z = 1;
+        L.frame.fillSize = 1;
+        L.frame.r_outer = 1000000000;
+        L.frame.r_inner = 0;
+        L.samples_per_launch = (uint32_t)cfg.spp_uniform;
+        L.frame.offset.x = L.frame.offset.y = 0;
+        L.frame.redraw = 0;
+        L.viewportSize.x = L.frame.size.x; L.viewportSize.y = L.frame.size.y;
+        const uint32_t temp_frame = L.frame.subframe_index;
+        P[0] = pass_from_lp(&L, (uint32_t)L.frame.size.x, (uint32_t)L.frame.size.y);
+        rc = run_passes(c, &L, P, 1);
+        L.frame.subframe_index = temp_frame;
+        L.frame.subframe_index++;
+        return rc;
+    }
+    const int inner_radius = cfg.r_inner, outer_radius = cfg.r_outer;
+    // periphery :137-157
+    L.frame.factor.x = 4; L.frame.factor.y = 4; L.frame.factor.z = 1;
+    L.frame.fillSize = 4;
+    L.frame.r_outer = 1000000000;
+    L.frame.r_inner = (float)outer_radius;
+    L.samples_per_launch = (uint32_t)cfg.spp_periphery;
+    L.frame.offset.x = L.frame.offset.y = 0;
+    L.frame.redraw = 0;
+    P[0] = pass_from_lp(&L, (uint32_t)(L.frame.size.x / 4), (uint32_t)(L.frame.size.y / 4));
+    // intermediate :160-187
+    const uint32_t temp_frame = L.frame.subframe_index;
+    L.frame.subframe_index = 0;
+    L.frame.factor.x = 2; L.frame.factor.y = 2; L.frame.factor.z = 1;
+    L.frame.fillSize = 2;
+    L.frame.r_outer = (float)(outer_radius + 2);
+    L.frame.r_inner = (float)inner_radius;
+    L.samples_per_launch = (uint32_t)cfg.spp_middle;
+    L.frame.offset.x = L.frame.c.x - (uint32_t)(outer_radius + 2);
+    L.frame.offset.y = L.frame.c.y - (uint32_t)(outer_radius + 2);
+    L.frame.redraw = 1;
+    P[1] = pass_from_lp(&L, (uint32_t)L.frame.r_outer, (uint32_t)L.frame.r_outer);
+    // fovea :189-209
+    L.frame.factor.x = 1; L.frame.factor.y = 1; L.frame.factor.z = 1;
+    L.frame.fillSize = 1;
+    L.frame.r_outer = (float)(inner_radius + 1);
+    L.frame.r_inner = 0;
+    L.samples_per_launch = (uint32_t)cfg.spp_fovea;
+    L.frame.offset.x = L.frame.c.x - (uint32_t)(inner_radius + 1);
+    L.frame.offset.y = L.frame.c.y - (uint32_t)(inner_radius + 1);
+    L.frame.redraw = 1;
+    P[2] = pass_from_lp(&L, (uint32_t)(L.frame.r_outer * 2), (uint32_t)(L.frame.r_outer * 2));
+    rc = run_passes(c, &L, P, 3);
+    L.frame.subframe_index = temp_frame;
+    L.frame.subframe_index++;
+    return rc;
+}
+
+int fovpt_synchronize(fovpt_ctx* c)
+{
+    if (!c) return FOVPT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return FOVPT_OK;
+}
+
+int fovpt_download(fovpt_ctx* c, const void* device_src, void* host_dst, size_t n_bytes)
+{
+    if (!c || !device_src || !host_dst) return FOVPT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(host_dst, device_src, n_bytes, hipMemcpyDeviceToHost));
+    return FOVPT_OK;
+}
+
+int fovpt_get_stats(fovpt_ctx* c, fovpt_stats* out)
+{
+    if (!c || !out) return FOVPT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    drain_events(c);
+    if (c->counters.p) {
+        Counters h;
+        HIPCHK(c, hipMemcpy(&h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost));
+        c->stats.radiance_rays = h.stat_radiance; c->stats.shadow_rays = h.stat_shadow; c->stats.paths = h.stat_paths;
+    }
+    *out = c->stats;
+    return FOVPT_OK;
+}
+
+int fovpt_reset_stats(fovpt_ctx* c)
+{
+    if (!c) return FOVPT_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    drain_events(c);
+    if (c->counters.p) HIPCHK(c, hipMemset((char*)c->counters.p + offsetof(Counters, stat_radiance), 0, sizeof(Counters) - offsetof(Counters, stat_radiance)));
+    c->stats.radiance_rays = c->stats.shadow_rays = c->stats.paths = c->stats.frames = 0;
+    c->stats.ms_generate = c->stats.ms_trace = c->stats.ms_shade = c->stats.ms_shadow = c->stats.ms_resolve = 0.0;
+    c->stats.n_trace_launches = c->stats.n_shadow_launches = 0;
+    return FOVPT_OK;
+}
+
+void* fovpt_stream(fovpt_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+// ---- host helpers ------------------------------------------------------------------------
+// ProbeData::BuildCDF, PT_sv5_/Probe.h:29-77.  Strictly sequential fp32 sums: the order is part of
+// the result.
+int fovpt_probe_build_cdf(int width, int height, const fovpt_float4* data,
+                          float* pdfValuesX, float* cdfValuesX, float* pdfValuesY, float* cdfValuesY)
+{
+    if (width <= 0 || height <= 0 || !data || !pdfValuesX || !cdfValuesX || !pdfValuesY || !cdfValuesY) return FOVPT_E_INVALID;
+    volatile float col_total = 0.0f;                  // volatile: keep every partial sum rounded to fp32
+    for (int row = 0; row < height; ++row) {
+        volatile float row_total = 0.0f;
+        float* pdf_row = pdfValuesX + (size_t)row * width;
+        float* cdf_row = cdfValuesX + (size_t)row * width;
+        const fovpt_float4* px = data + (size_t)row * width;
+        for (int k = 0; k < width; ++k) {
+            const float lum = px[k].x * 0.3f + px[k].y * 0.6f + px[k].z * 0.1f;   // Luminance, maths.h:165-168
+            row_total = row_total + lum;
+            pdf_row[k] = lum;
+            cdf_row[k] = row_total;
+        }
+        const float inv = 1.0f / row_total;
+        for (int k = 0; k < width; ++k) { pdf_row[k] *= inv; cdf_row[k] *= inv; }
+        col_total = col_total + row_total;
+        pdfValuesY[row] = row_total;
+        cdfValuesY[row] = col_total;
+    }
+    const float total = col_total;
+    for (int row = 0; row < height; ++row) { cdfValuesY[row] /= total; pdfValuesY[row] /= total; }
+    return FOVPT_OK;
+}
+
+// sutil::Camera::UVWFrame, sutil/Camera.cpp:32-44
+int fovpt_camera_uvw(const fovpt_float3* eye, const fovpt_float3* lookat, const fovpt_float3* up,
+                     float fovY, float aspect, fovpt_float3* U, fovpt_float3* V, fovpt_float3* W)
+{
+    if (!eye || !lookat || !up || !U || !V || !W) return FOVPT_E_INVALID;
+    const float wx = lookat->x - eye->x, wy = lookat->y - eye->y, wz = lookat->z - eye->z;
+    const float wlen = sqrtf(wx * wx + wy * wy + wz * wz);
+    float ux = wy * up->z - wz * up->y, uy = wz * up->x - wx * up->z, uz = wx * up->y - wy * up->x;    // cross(W, up)
+    float inv = 1.0f / sqrtf(ux * ux + uy * uy + uz * uz);
+    ux *= inv; uy *= inv; uz *= inv;
+    float vx = uy * wz - uz * wy, vy = uz * wx - ux * wz, vz = ux * wy - uy * wx;                      // cross(U, W)
+    inv = 1.0f / sqrtf(vx * vx + vy * vy + vz * vz);
+    vx *= inv; vy *= inv; vz *= inv;
+    const float vlen = wlen * tanf(0.5f * fovY * 3.14159265358979323846f / 180.0f);
+    vx *= vlen; vy *= vlen; vz *= vlen;
+    const float ulen = vlen * aspect;
+    ux *= ulen; uy *= ulen; uz *= ulen;
+    U->x = ux; U->y = uy; U->z = uz; V->x = vx; V->y = vy; V->z = vz; W->x = wx; W->y = wy; W->z = wz;
+    return FOVPT_OK;
+}
+
+int fovpt_debug_math(fovpt_ctx* c, int op, const float* a, const float* b, float* out, size_t n)
+{
+    if (!c || !a || !out) return FOVPT_E_INVALID;
+    if (n == 0) return FOVPT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIPCHK(c, hipMalloc(&da, n * 4)); HIPCHK(c, hipMalloc(&db, n * 4)); HIPCHK(c, hipMalloc(&dout, n * 4));
+    HIPCHK(c, hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice));
+    if (b) HIPCHK(c, hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice));
+    else HIPCHK(c, hipMemset(db, 0, n * 4));
+    fovpt_launch_math(c->stream, op, da, db, dout, n);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    return FOVPT_OK;
+}
+
+}  // extern "C"

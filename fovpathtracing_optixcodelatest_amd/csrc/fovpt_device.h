@@ -1,0 +1,137 @@
+// fovpt_device.h -- structures shared by the host API (fovpt_api.hip), the LBVH builder
+// (bvh_build.hip) and the wavefront kernels (wavefront.hip).  gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fovpt.h"
+
+#define FOVPT_WAVE 64
+#define FOVPT_BLOCK 256
+#define FOVPT_LEAF_MAX 4          // triangles per BVH leaf
+#define FOVPT_STACK_LDS 16        // traversal stack entries kept in LDS per lane
+#define FOVPT_STACK_SPILL 48      // deeper entries go to a per-lane slice in HBM
+#define FOVPT_MAX_PASSES 3
+#define FOVPT_MAX_ITERS 63         // wavefront iterations per frame (max_depth + catcher pass-throughs)
+
+// One triangle in BVH leaf order, pre-subtracted edges (exactly v1-v0 and v2-v0 in fp32,
+// so Moeller-Trumbore gives the same bits as the contract in include/fovpt.h / oracle).
+struct alignas(16) TriRec {
+    float v0x, v0y, v0z, e1x;
+    float e1y, e1z, e2x, e2y;
+    float e2z;
+    uint32_t prim;                // global primitive id (tie-break key)
+    uint32_t mesh;
+    uint32_t pad;
+};                                // 48 B
+static_assert(sizeof(TriRec) == 48, "TriRec");
+
+// BVH2 node carrying both children's boxes (one 64-B line per visit).
+// child >= 0: internal node index;  child < 0: leaf, ~child = (first_tri << 3) | (count-1).
+struct alignas(16) BvhNode {
+    float lo0x, lo0y, lo0z, hi0x;
+    float hi0y, hi0z, lo1x, lo1y;
+    float lo1z, hi1x, hi1y, hi1z;
+    int32_t c0, c1;
+    uint32_t pad0, pad1;
+};                                // 64 B
+static_assert(sizeof(BvhNode) == 64, "BvhNode");
+
+struct TexDev {
+    const uint32_t* px;
+    int32_t w, h;
+};
+
+struct MeshDev {                  // the SBT record of the reference (LaunchParams.h:38-47), minus geometry
+    fovpt_material material;      // 104 B
+    int32_t texture_id;           // <0: none
+    int32_t has_texcoord;
+};                                // 112 B
+
+struct SceneView {
+    const BvhNode* nodes;
+    const TriRec* tris;           // leaf order
+    const float2* tri_tc;         // 3 per global primitive id (or null)
+    const MeshDev* meshes;
+    const TexDev* textures;
+    uint32_t num_tris;
+    uint32_t any_catcher;
+};
+
+struct PassDev {                  // one optixLaunch worth of parameters
+    uint32_t gw, gh;              // launch grid
+    uint32_t fx, fy, fz;          // frame.factor
+    int32_t fill;                 // frame.fillSize
+    uint32_t offx, offy;          // frame.offset
+    float r_inner, r_outer;
+    uint32_t spp;                 // samples_per_launch
+    uint32_t subframe;            // frame.subframe_index
+    uint32_t redraw;              // frame.redraw
+    uint32_t slot_base;           // first sample slot of this pass
+    uint32_t launch_base;         // first launch record of this pass
+    uint32_t pad;
+};
+
+struct FrameDev {
+    PassDev pass[FOVPT_MAX_PASSES];
+    int32_t npass;
+    int32_t w, h;                 // frame.size
+    uint32_t cx, cy;              // frame.c
+    float eye[3], U[3], V[3], W[3];
+    fovpt_probe probe;            // device pointers
+    fovpt_float4* accum;
+    uint32_t* frame;
+    uint32_t total_slots;
+    int32_t max_depth;
+    int32_t accumulate;
+    int32_t rank, world, tile_w, tile_h;
+};
+
+// Per-sample-slot path state (SoA, 16-B vectors so every access is one dwordx4).
+struct PathState {
+    float4* ray_o;      // origin.xyz, unused
+    float4* ray_d;      // direction.xyz, unused
+    float4* thr;        // pathThroughput.xyz, rayEta
+    uint4* rng;         // Random.seed1, Random.seed2, stateFlags | depth << 8, unused
+    float4* hit;        // t, u, v, tri position in leaf order as bits (0xffffffff = miss)
+    float4* direct;     // directLight
+    float4* indirect;   // indirectLight
+    float4* alpha;      // prd.alpha
+    float4* backplate;  // per launch record: backplate of the last sample (deviceProgram.cu:495)
+};
+
+// Shadow (occlusion) ray queue, indexed by queue position.
+struct ShadowQueue {
+    float4* o;          // origin.xyz, slot as bits
+    float4* d;          // direction.xyz, target as bits (0 direct, 1 indirect, 2 alpha)
+    float4* val_vis;    // value added when NOT occluded
+    float4* val_occ;    // value added when occluded
+};
+
+struct Counters {       // device-resident, zeroed per frame except the stats block
+    uint32_t q[FOVPT_MAX_ITERS + 1];   // radiance queue sizes per iteration (q[0] = camera rays)
+    uint32_t sq[FOVPT_MAX_ITERS + 1];  // shadow queue sizes per iteration
+    unsigned long long stat_radiance, stat_shadow, stat_paths;
+};
+
+// ---- launchers implemented in wavefront.hip / bvh_build.hip -------------------------------
+struct BvhBuildResult {
+    BvhNode* nodes;
+    TriRec* tris;
+    uint32_t num_nodes;           // allocated node slots (n-1 Karras nodes, sparse after collapse)
+    uint32_t max_depth;
+    size_t node_bytes, tri_bytes;
+};
+
+// flat: 9 floats per triangle (v0,v1,v2), mesh_of_prim: mesh id per triangle.  All device pointers.
+hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* mesh_of_prim, uint32_t n,
+                            BvhBuildResult* out, char* err, size_t errlen);
+
+void fovpt_launch_generate(hipStream_t st, const FrameDev& fd, PathState ps, uint32_t* queue0, Counters* cnt, uint32_t total_slots, int grid);
+void fovpt_launch_trace(hipStream_t st, SceneView sc, PathState ps, const uint32_t* queue, Counters* cnt, int depth, int* spill, int grid);
+void fovpt_launch_shade(hipStream_t st, const FrameDev& fd, SceneView sc, PathState ps, const uint32_t* queue_in, uint32_t* queue_out,
+                        ShadowQueue sq, Counters* cnt, int depth, int grid);
+void fovpt_launch_shadow(hipStream_t st, SceneView sc, PathState ps, ShadowQueue sq, Counters* cnt, int depth, int* spill, int grid);
+void fovpt_launch_resolve(hipStream_t st, const FrameDev& fd, PathState ps);
+void fovpt_launch_math(hipStream_t st, int op, const float* a, const float* b, float* out, size_t n);

@@ -1,0 +1,934 @@
+// wavefront.hip -- the foveated path-tracing launch as a wavefront pipeline on gfx950.
+//
+// What the reference runs as ONE OptiX raygen thread per launch index with recursive
+// optixTrace calls (PT_sv5_/deviceProgram.cu:392-732) is split here into queue-driven stages,
+// one sample *slot* = (pass, launch index, sample number) per work item:
+//
+//   generate      __raygen__renderFrame :394-495   seed, ring test, jitter, camera ray, backplate
+//   trace         optixTrace RADIANCE   :196-222   LBVH closest hit, LDS-staged stack
+//   shade         __closesthit__/__miss__radiance :253-282,619-732 + SampleLights :303-344
+//                 + Disney BSDF (Disney.cuh) + probe NEE (Probe.cuh); emits the shadow ray and
+//                 the continuation ray, ballot-compacted into the next queues
+//   shadow        optixTrace OCCLUSION  :224-248,284-300   any front-facing candidate
+//   resolve       :541-616              ordered per-launch sample reduction, pass-ordered
+//                                       block fill, exposure, Reinhard, sRGB, rgba8
+//
+// The three foveation passes of SampleRenderer::render() (SimplePathtracer.cpp:133-213) are
+// one job: their slots share the queues, and resolve gives every pixel to its last writer in
+// the reference's launch order (P, then M, then F; within a launch ascending y, x).
+//
+// Arithmetic: fp32 with the reference's operation order, -ffp-contract=off, IEEE divide and
+// sqrt, transcendental functions from include/fovpt_detmath.h.  The only fused multiply-adds
+// are the explicit ones in the (conservative) box test.
+#include "fovpt_device.h"
+#include "../../include/fovpt_detmath.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// fp32 vector helpers with the semantics of sutil/vec_math.h
+// ------------------------------------------------------------------------------------------
+struct V3 { float x, y, z; };
+__device__ inline V3 v3(float x, float y, float z) { V3 r = {x, y, z}; return r; }
+__device__ inline V3 v3(float s) { return v3(s, s, s); }
+__device__ inline V3 v3(const float4& a) { return v3(a.x, a.y, a.z); }
+__device__ inline V3 v3(const fovpt_float3& a) { return v3(a.x, a.y, a.z); }
+__device__ inline V3 neg(const V3& a) { return v3(-a.x, -a.y, -a.z); }
+__device__ inline V3 operator+(const V3& a, const V3& b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ inline V3 operator-(const V3& a, const V3& b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ inline V3 operator*(const V3& a, const V3& b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ inline V3 operator*(const V3& a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ inline V3 operator*(float s, const V3& a) { return v3(a.x * s, a.y * s, a.z * s); }
+__device__ inline V3 sub_sv(float a, const V3& b) { return v3(a - b.x, a - b.y, a - b.z); }          // float - float3
+__device__ inline V3 add_vs(const V3& a, float b) { return v3(a.x + b, a.y + b, a.z + b); }          // float3 + float
+__device__ inline V3 div_vs(const V3& a, float s) { float inv = 1.0f / s; return a * inv; }          // vec_math.h:487
+__device__ inline float dot(const V3& a, const V3& b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ inline V3 cross(const V3& a, const V3& b)
+{ return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+__device__ inline V3 normalize(const V3& v) { float invLen = 1.0f / sqrtf(dot(v, v)); return v * invLen; }
+__device__ inline float clampf(float f, float a, float b) { return fmaxf(a, fminf(f, b)); }
+__device__ inline V3 clamp3(const V3& v, float a, float b) { return v3(clampf(v.x, a, b), clampf(v.y, a, b), clampf(v.z, a, b)); }
+__device__ inline float lerpf(float a, float b, float t) { return a + t * (b - a); }
+__device__ inline V3 lerp3(const V3& a, const V3& b, float t) { return a + t * (b - a); }
+__device__ inline float sqr(float a) { return a * a; }
+__device__ inline float4 f4(const V3& a, float w) { return make_float4(a.x, a.y, a.z, w); }
+
+#define kPi (3.141592653589793f)
+#define k2Pi (3.141592653589793f * 2.0f)
+#define kInvPi (1.0f / kPi)
+#define kInv2Pi (1.0f / k2Pi)
+
+// ------------------------------------------------------------------------------------------
+// RNG (cuda/random.h:34-59,101-104; maths.h:170-227)
+// ------------------------------------------------------------------------------------------
+__device__ inline uint32_t tea4(uint32_t v0, uint32_t v1)
+{
+    uint32_t s0 = 0;
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+        s0 += 0x9e3779b9u;
+        v0 += ((v1 << 4) + 0xa341316cu) ^ (v1 + s0) ^ ((v1 >> 5) + 0xc8013ea4u);
+        v1 += ((v0 << 4) + 0xad90777du) ^ (v0 + s0) ^ ((v0 >> 5) + 0x7e95761eu);
+    }
+    return v0;
+}
+__device__ inline float rnd(uint32_t& prev)
+{
+    prev = 1664525u * prev + 1013904223u;
+    return (float)(prev & 0x00FFFFFFu) / (float)0x01000000;
+}
+struct Rng {
+    uint32_t s1, s2;
+    __device__ inline uint32_t next()
+    {
+        s1 = (s2 ^ ((s1 << 5) | (s1 >> 27))) ^ (s1 * s2);
+        s2 = s1 ^ ((s2 << 12) | (s2 >> 20));
+        return s1;
+    }
+    __device__ inline float randf()
+    {
+        // maths.h:199-210: value * (1/float(0xffffffff)), clamp to [0, 0.999999]
+        return clampf((float)next() * (1.0f / 4294967296.0f), 0.f, 0.999999f);
+    }
+    __device__ inline float randf01()      // Randf(0,1), maths.h:213-217
+    {
+        float t = randf();
+        return (1.0f - t) * 0.0f + t * 1.0f;
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// Probe (Probe.cuh)
+// ------------------------------------------------------------------------------------------
+__device__ inline void probe_dir_to_uv(const V3& dir, float& u, float& v)     // :38-46
+{
+    float theta = fovpt_dm_acosf(clampf(dir.y, -1.0f, 1.0f));
+    float phi = (dir.x == 0.0f && dir.z == 0.0f) ? 0.0f : fovpt_dm_atan2f(dir.z, dir.x);
+    u = (kPi + phi) * kInvPi * 0.5f;
+    v = theta * kInvPi;
+}
+__device__ inline float4 probe_eval(const fovpt_probe& pr, float u, float v)  // :61-67
+{
+    int px = max(0, min((int)(u * pr.width), pr.width - 1));
+    int py = max(0, min((int)(v * pr.height), pr.height - 1));
+    return ((const float4*)pr.data)[py * pr.width + px];
+}
+__device__ inline int lower_bound(const float* __restrict__ a, int lower, int upper, float value)   // :119-136
+{
+    while (lower < upper) {
+        int mid = lower + (upper - lower) / 2;
+        if (a[mid] < value) lower = mid + 1;
+        else upper = mid;
+    }
+    return lower;
+}
+__device__ inline void probe_sample(const fovpt_probe& pr, V3& dir, V3& color, float& pdf, Rng& rng)   // :138-169
+{
+    float r1 = rng.randf01();
+    float r2 = rng.randf01();
+    int row = lower_bound(pr.cdfValuesY, 0, pr.height, r1);
+    int col = lower_bound(pr.cdfValuesX, row * pr.width, (row + 1) * pr.width, r2) - row * pr.width;
+    color = v3(((const float4*)pr.data)[row * pr.width + col]);
+    pdf = pr.pdfValuesX[row * pr.width + col] * pr.pdfValuesY[row];
+    float u = col / float(pr.width);
+    float v = row / float(pr.height);
+    float sinTheta, cosTheta;
+    fovpt_dm_sincos(v * kPi, &sinTheta, &cosTheta);
+    if (sinTheta == 0.0f) pdf = 0.0f;
+    else pdf *= pr.width * pr.height / (2.0f * kPi * kPi * sinTheta);
+    // ProbeUVToDir :48-58 (theta = v*kPi is the same value as above)
+    float sinPhi, cosPhi;
+    fovpt_dm_sincos(u * 2.0f * kPi, &sinPhi, &cosPhi);
+    dir = v3(-sinTheta * cosPhi, cosTheta, -sinTheta * sinPhi);
+}
+
+// ------------------------------------------------------------------------------------------
+// Disney BSDF (Disney.cuh)
+// ------------------------------------------------------------------------------------------
+typedef fovpt_material Mat;
+
+__device__ inline void basis_from_vector(const V3& w, V3& u, V3& v)          // maths.h:94-108
+{
+    if (fabsf(w.x) > fabsf(w.y)) {
+        float invLen = (float)(1.0 / (double)sqrtf(w.x * w.x + w.z * w.z));
+        u = v3(-w.z * invLen, 0.0f, w.x * invLen);
+    } else {
+        float invLen = (float)(1.0 / (double)sqrtf(w.y * w.y + w.z * w.z));
+        u = v3(0.0f, w.z * invLen, -w.y * invLen);
+    }
+    v = cross(w, u);
+}
+__device__ inline V3 safe_normalize(const V3& a)                              // maths.h:144-156
+{
+    float m = dot(a, a);
+    if ((double)m > 0.0) return a * (float)(1.0 / (double)sqrtf(m));
+    return v3(0.0f);
+}
+__device__ inline float schlick(float u)                                      // Disney.cuh:51-56
+{
+    float m = clampf(1 - u, 0.0f, 1.0f);
+    float m2 = m * m;
+    return m2 * m2 * m;
+}
+__device__ inline float gtr1(float NDotH, float a)                            // :58-64
+{
+    if (a >= 1) return kInvPi;
+    float a2 = a * a;
+    float t = 1 + (a2 - 1) * NDotH * NDotH;
+    return (a2 - 1) / (kPi * fovpt_dm_logf(a2) * t);
+}
+__device__ inline float gtr2(float NDotH, float a)                            // :66-71
+{
+    float a2 = a * a;
+    float t = 1.0f + (a2 - 1.0f) * NDotH * NDotH;
+    return a2 / (kPi * t * t);
+}
+__device__ inline float smith_ggx(float NDotv, float alphaG)                  // :73-78
+{
+    float a = alphaG * alphaG;
+    float b = NDotv * NDotv;
+    return 1 / (NDotv + sqrtf(a + b - a * b));
+}
+__device__ inline float fresnel(float VDotN, float etaI, float etaT)          // Fr, :81-98
+{
+    float SinThetaT2 = sqr(etaI / etaT) * (1.0f - VDotN * VDotN);
+    if (SinThetaT2 > 1.0f) return 1.0f;
+    float LDotN = sqrtf(1.0f - SinThetaT2);
+    float eta = etaT / etaI;
+    float r1 = (VDotN - eta * LDotN) / (VDotN + eta * LDotN);
+    float r2 = (LDotN - eta * VDotN) / (LDotN + eta * VDotN);
+    return 0.5f * (sqr(r1) + sqr(r2));
+}
+__device__ float bsdf_pdf(const Mat& mat, float etaI, float etaO, const V3& n, const V3& V, const V3& L)   // :152-193
+{
+    if (dot(L, n) <= 0.0f) {
+        float bsdfPdf = 0.0f;
+        float brdfPdf = kInv2Pi * mat.subsurface * 0.5f;
+        return lerpf(brdfPdf, bsdfPdf, mat.transmission);
+    }
+    float F = fresnel(dot(n, V), etaI, etaO);
+    const float a = fmaxf(0.001f, mat.roughness);
+    const V3 half = safe_normalize(L + V);
+    const float cosThetaHalf = fabsf(dot(half, n));
+    const float pdfHalf = gtr2(cosThetaHalf, a) * cosThetaHalf;
+    float pdfSpec = 0.25f * pdfHalf / fmaxf(1.e-6f, dot(L, half));
+    float pdfDiff = fabsf(dot(L, n)) * kInvPi * (1.0f - mat.subsurface);
+    float bsdfPdf = pdfSpec * F;
+    float brdfPdf = lerpf(pdfDiff, pdfSpec, 0.5f);
+    return lerpf(brdfPdf, bsdfPdf, mat.transmission);
+}
+__device__ inline V3 ggx_reflect(const Mat& mat, float r1, float r2, const V3& U, const V3& V, const V3& N, const V3& view)
+{
+    // shared by the two "sample specular" branches, Disney.cuh:211-226 and :287-307
+    const float a = fmaxf(0.001f, mat.roughness);
+    const float phiHalf = r1 * k2Pi;
+    const float cosThetaHalf = sqrtf((1.0f - r2) / (1.0f + (sqr(a) - 1.0f) * r2));
+    const float sinThetaHalf = sqrtf(fmaxf(0.0f, 1.0f - sqr(cosThetaHalf)));
+    float sinPhiHalf, cosPhiHalf;
+    fovpt_dm_sincos(phiHalf, &sinPhiHalf, &cosPhiHalf);
+    V3 half = U * (sinThetaHalf * cosPhiHalf) + V * (sinThetaHalf * sinPhiHalf) + N * cosThetaHalf;
+    if (dot(half, view) <= 0.0f) half = half * -1.0f;
+    return 2.0f * dot(view, half) * half - view;
+}
+// returns pdf; light = sampled direction
+__device__ float bsdf_sample(const Mat& mat, float etaI, float etaO, const V3& U, const V3& V, const V3& N,
+                             const V3& view, V3& light, Rng& rng)             // :197-315
+{
+    if (rng.randf() < mat.transmission) {
+        float F = fresnel(dot(N, view), etaI, etaO);
+        if (rng.randf() < F) {
+            float r1 = rng.randf01();
+            float r2 = rng.randf01();
+            light = ggx_reflect(mat, r1, r2, U, V, N, view);
+        } else {
+            // Refract, :36-49
+            float eta = etaI / etaO;
+            float cosThetaI = dot(N, view);
+            float sin2ThetaI = fmaxf(0.0f, 1.0f - cosThetaI * cosThetaI);
+            float sin2ThetaT = eta * eta * sin2ThetaI;
+            if (sin2ThetaT >= 1) return 0.0f;
+            float cosThetaT = sqrtf(1.0f - sin2ThetaT);
+            light = eta * neg(view) + (eta * cosThetaI - cosThetaT) * N;
+            return (1.0f - F) * mat.transmission;
+        }
+    } else {
+        float r1 = rng.randf01();
+        float r2 = rng.randf01();
+        if (rng.randf() < 0.5f) {
+            if (rng.randf() < mat.subsurface) {
+                // UniformSampleHemisphere, maths.h:243-254
+                float z = rng.randf01();
+                float w = sqrtf(1.0f - z * z);
+                float phi = k2Pi * rng.randf01();
+                float s, c;
+                fovpt_dm_sincos(phi, &s, &c);
+                float x = c * w, y = s * w;
+                light = U * x + V * y - N * z;
+            } else {
+                // CosineSampleHemisphere, maths.h:256-277
+                float r = sqrtf(r1);
+                float theta = k2Pi * r2;
+                float s, c;
+                fovpt_dm_sincos(theta, &s, &c);
+                float sx = r * c, sy = r * s;
+                float z = sqrtf(fmaxf(0.0f, 1.0f - sx * sx - sy * sy));
+                light = U * sx + V * sy + N * z;
+            }
+        } else {
+            light = ggx_reflect(mat, r1, r2, U, V, N, view);
+        }
+    }
+    return bsdf_pdf(mat, etaI, etaO, N, view, light);
+}
+__device__ V3 bsdf_eval(const Mat& mat, const V3& albedo, float etaI, float etaO, const V3& N, const V3& V, const V3& L)   // :318-427
+{
+    float NDotL = dot(N, L);
+    float NDotV = dot(N, V);
+    V3 H = normalize(L + V);
+    float NDotH = dot(N, H);
+    float LDotH = dot(L, H);
+    V3 Cdlin = albedo;
+    float Cdlum = (float)(.3 * (double)Cdlin.x + .6 * (double)Cdlin.y + .1 * (double)Cdlin.z);
+    V3 Ctint = Cdlum > 0.0f ? div_vs(Cdlin, Cdlum) : v3(1.0f);
+    V3 Cspec0 = lerp3((float)((double)mat.specular * .08) * lerp3(v3(1.0f), Ctint, mat.specularTint), Cdlin, mat.metallic);
+    V3 bsdf = v3(0.0f);
+    V3 brdf = v3(0.0f);
+    if (mat.transmission > 0.0f) {
+        if (NDotL <= 0) {
+            float F = fresnel(NDotV, etaI, etaO);
+            bsdf = v3(mat.transmission * (1.0f - F) / fabsf(NDotL) * (1.0f - mat.metallic));
+        } else {
+            float a = fmaxf(0.001f, mat.roughness);
+            float Ds = gtr2(NDotH, a);
+            float FH = fresnel(LDotH, etaI, etaO);
+            V3 Fs = lerp3(Cspec0, v3(1.0f), FH);
+            float Gs = smith_ggx(NDotV, a) * smith_ggx(NDotL, a);
+            bsdf = Gs * Fs * Ds;
+        }
+    }
+    if (mat.transmission < 1.0f) {
+        if (NDotL <= 0) {
+            if (mat.subsurface > 0.0f) {
+                V3 s = v3(sqrtf(mat.color.x), sqrtf(mat.color.y), sqrtf(mat.color.z));
+                float FL = schlick(fabsf(NDotL)), FV = schlick(NDotV);
+                float Fd = (1.0f - 0.5f * FL) * (1.0f - 0.5f * FV);
+                brdf = kInvPi * s * mat.subsurface * Fd * (1.0f - mat.metallic);
+            }
+        } else {
+            float a = fmaxf(0.001f, mat.roughness);
+            float Ds = gtr2(NDotH, a);
+            float FH = schlick(LDotH);
+            V3 Fs = lerp3(Cspec0, v3(1.f), FH);
+            float Gs = smith_ggx(NDotV, a) * smith_ggx(NDotL, a);
+            float FL = schlick(NDotL), FV = schlick(NDotV);
+            float Fd90 = (float)(0.5 + (double)(2.0f * LDotH * LDotH * mat.roughness));
+            float Fd = lerpf(1.0f, Fd90, FL) * lerpf(1.0f, Fd90, FV);
+            float Dr = gtr1(NDotH, lerpf(.1f, .001f, mat.clearcoatGloss));
+            float Fc = lerpf(.04f, 1.0f, FH);
+            float Gr = smith_ggx(NDotL, .25f) * smith_ggx(NDotV, .25f);
+            brdf = add_vs(kInvPi * Fd * Cdlin * (1.0f - mat.metallic) * (1.0f - mat.subsurface) + Gs * Fs * Ds,
+                          mat.clearcoat * Gr * Fc * Dr);
+        }
+    }
+    return lerp3(brdf, bsdf, mat.transmission);
+}
+
+// ------------------------------------------------------------------------------------------
+// wavefront plumbing
+// ------------------------------------------------------------------------------------------
+// Ballot compaction: every lane with pred gets a distinct position; one atomic per wave.
+__device__ inline uint32_t wave_append(uint32_t* counter, bool pred)
+{
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return 0u;
+    const uint32_t lane = __lane_id();
+    const uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, leader);
+    return base + prefix;
+}
+
+__device__ inline bool launch_owned(const FrameDev& fd, int p, uint32_t lx, uint32_t ly)
+{
+    if (fd.world <= 1) return true;
+    uint32_t tx = lx / (uint32_t)fd.tile_w, ty = ly / (uint32_t)fd.tile_h;
+    return (int)((tx + 3u * ty + (uint32_t)p) % (uint32_t)fd.world) == fd.rank;
+}
+
+// ring test of deviceProgram.cu:433-440 on the block's top-left pixel (uint arithmetic wraps)
+__device__ inline bool ring_alive(const FrameDev& fd, const PassDev& P, uint32_t lx, uint32_t ly, uint32_t& ix, uint32_t& iy)
+{
+    ix = lx * P.fx + P.offx;
+    iy = ly * P.fy + P.offy;
+    const float dx = (float)ix - (float)fd.cx, dy = (float)iy - (float)fd.cy, dz = 0.0f - 0.0f;
+    const float range = sqrtf(dx * dx + dy * dy + dz * dz);
+    return !(range < P.r_inner || range > P.r_outer);
+}
+
+// ---- generate ----------------------------------------------------------------------------
+__global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, PathState ps, uint32_t* __restrict__ queue0,
+                                                          Counters* __restrict__ cnt, uint32_t total_slots)
+{
+    for (uint32_t base = blockIdx.x * FOVPT_BLOCK; base < total_slots; base += gridDim.x * FOVPT_BLOCK) {
+        const uint32_t slot = base + threadIdx.x;
+        bool live = slot < total_slots;
+        int p = 0;
+        uint32_t lx = 0, ly = 0, s = 0, ix = 0, iy = 0;
+        if (live) {
+            while (p + 1 < fd.npass && slot >= fd.pass[p + 1].slot_base) p++;
+            const PassDev& P = fd.pass[p];
+            const uint32_t rel = slot - P.slot_base;
+            const uint32_t li = rel / P.spp;
+            s = rel - li * P.spp;
+            ly = li / P.gw;
+            lx = li - ly * P.gw;
+            live = ring_alive(fd, P, lx, ly, ix, iy) && launch_owned(fd, p, lx, ly);
+        }
+        if (live) {
+            const PassDev& P = fd.pass[p];
+            uint32_t seed = tea4(ly * (uint32_t)fd.w + lx, P.subframe);        // :411
+            for (uint32_t k = 0; k < s; k++) { (void)rnd(seed); (void)rnd(seed); }   // earlier samples' jitter draws
+            Rng rng;                                                            // Random(seed), maths.h:176-180
+            rng.s1 = 315645664u + seed;
+            rng.s2 = rng.s1 ^ 0x13ab45feu;
+            const float jx = rnd(seed);                                         // :479, x first
+            const float jy = rnd(seed);
+            const float dx = 2.0f * (((float)ix + jx) / (float)fd.w) - 1.0f;    // :483-486
+            const float dy = 2.0f * (((float)iy + jy) / (float)fd.h) - 1.0f;
+            const V3 U = v3(fd.U[0], fd.U[1], fd.U[2]), V = v3(fd.V[0], fd.V[1], fd.V[2]), W = v3(fd.W[0], fd.W[1], fd.W[2]);
+            const V3 dir = normalize(dx * U + dy * V + W);                      // :491
+            ps.ray_o[slot] = make_float4(fd.eye[0], fd.eye[1], fd.eye[2], 0.f);
+            ps.ray_d[slot] = f4(dir, 0.f);
+            ps.thr[slot] = make_float4(1.f, 1.f, 1.f, 1.0f);                    // pathThroughput, rayEta
+            ps.rng[slot] = make_uint4(rng.s1, rng.s2, 0u, 0u);                  // stateFlags 0, depth 0
+            ps.direct[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ps.indirect[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+            ps.alpha[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (s == P.spp - 1) {                                               // backplate of the last sample, :495
+                float u, v;
+                probe_dir_to_uv(dir, u, v);
+                ps.backplate[P.launch_base + ly * P.gw + lx] = probe_eval(fd.probe, u, v);
+            }
+        }
+        const uint32_t pos = wave_append(&cnt->q[0], live);
+        if (live) queue0[pos] = slot;
+    }
+}
+
+// ---- traversal ---------------------------------------------------------------------------
+struct Stack {
+    int* lds;          // this lane's column: lds[k * FOVPT_BLOCK]
+    int* spill;        // this lane's slice in HBM: spill[k * stride]
+    uint32_t stride;
+    int sp;
+    __device__ inline void push(int v)
+    {
+        if (sp < FOVPT_STACK_LDS) lds[sp * FOVPT_BLOCK] = v;
+        else spill[(size_t)(sp - FOVPT_STACK_LDS) * stride] = v;
+        sp++;
+    }
+    __device__ inline int pop()
+    {
+        sp--;
+        return sp < FOVPT_STACK_LDS ? lds[sp * FOVPT_BLOCK] : spill[(size_t)(sp - FOVPT_STACK_LDS) * stride];
+    }
+};
+
+struct RayT {
+    float ox, oy, oz, dx, dy, dz;
+    float ix, iy, iz;          // safe reciprocal direction for the box test
+    float nox, noy, noz;       // -origin * reciprocal
+};
+
+__device__ inline float safe_rcp(float d)
+{
+    const float a = fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d;
+    return 1.0f / a;
+}
+__device__ inline void ray_setup(RayT& r, const float4& o, const float4& d)
+{
+    r.ox = o.x; r.oy = o.y; r.oz = o.z; r.dx = d.x; r.dy = d.y; r.dz = d.z;
+    r.ix = safe_rcp(d.x); r.iy = safe_rcp(d.y); r.iz = safe_rcp(d.z);
+    r.nox = -o.x * r.ix; r.noy = -o.y * r.iy; r.noz = -o.z * r.iz;
+}
+// conservative slab test (boxes are padded at build time); returns entry distance in tn
+__device__ inline bool box_hit(const RayT& r, float lx, float ly, float lz, float hx, float hy, float hz, float tmin, float tmax, float& tn)
+{
+    const float ax = __builtin_fmaf(lx, r.ix, r.nox), bx = __builtin_fmaf(hx, r.ix, r.nox);
+    const float ay = __builtin_fmaf(ly, r.iy, r.noy), by = __builtin_fmaf(hy, r.iy, r.noy);
+    const float az = __builtin_fmaf(lz, r.iz, r.noz), bz = __builtin_fmaf(hz, r.iz, r.noz);
+    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+    const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    tn = t0;
+    return t0 <= t1 * 1.0000004f;
+}
+
+// Moeller-Trumbore, identical operation order to the parity contract (oracle intersect_tri)
+__device__ inline bool tri_hit(const RayT& r, const TriRec& T, float& t, float& u, float& v, float& det)
+{
+    const V3 d = v3(r.dx, r.dy, r.dz);
+    const V3 e1 = v3(T.e1x, T.e1y, T.e1z), e2 = v3(T.e2x, T.e2y, T.e2z);
+    const V3 p = cross(d, e2);
+    det = dot(e1, p);
+    if (det == 0.0f) return false;
+    const float inv = 1.0f / det;
+    const V3 s = v3(r.ox, r.oy, r.oz) - v3(T.v0x, T.v0y, T.v0z);
+    u = dot(s, p) * inv;
+    if (!(u >= 0.0f && u <= 1.0f)) return false;
+    const V3 q = cross(s, e1);
+    v = dot(d, q) * inv;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
+    t = dot(e2, q) * inv;
+    return true;
+}
+
+__device__ inline TriRec load_tri(const TriRec* __restrict__ tris, uint32_t i)
+{
+    const float4* p = (const float4*)(tris + i);
+    const float4 a = p[0], b = p[1], c = p[2];
+    TriRec T;
+    T.v0x = a.x; T.v0y = a.y; T.v0z = a.z; T.e1x = a.w;
+    T.e1y = b.x; T.e1z = b.y; T.e2x = b.z; T.e2y = b.w;
+    T.e2z = c.x; T.prim = __float_as_uint(c.y); T.mesh = __float_as_uint(c.z); T.pad = 0;
+    return T;
+}
+
+#define TMIN 0.01f     // deviceProgram.cu:41
+#define TMAX 1e16f     // deviceProgram.cu:42
+
+template <bool ANY_HIT>
+__device__ inline void traverse(const SceneView& sc, const RayT& r, Stack& st, float& best_t, float& best_u, float& best_v,
+                                uint32_t& best_pos, uint32_t& best_prim, bool& occluded)
+{
+    st.sp = 0;
+    int cur = 0;                       // root
+    for (;;) {
+        // ---- internal nodes
+        while (cur >= 0) {
+            const float4* np = (const float4*)(sc.nodes + cur);
+            const float4 n0 = np[0], n1 = np[1], n2 = np[2];
+            const int4 n3 = ((const int4*)np)[3];
+            const float lim = ANY_HIT ? TMAX : fminf(TMAX, best_t * 1.000001f);
+            float t0, t1;
+            const bool h0 = box_hit(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, TMIN, lim, t0);
+            const bool h1 = box_hit(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, TMIN, lim, t1);
+            if (h0 && h1) {
+                const bool swap = t1 < t0;
+                st.push(swap ? n3.x : n3.y);
+                cur = swap ? n3.y : n3.x;
+            } else if (h0) {
+                cur = n3.x;
+            } else if (h1) {
+                cur = n3.y;
+            } else {
+                if (st.sp == 0) return;
+                cur = st.pop();
+            }
+        }
+        // ---- leaf
+        {
+            const uint32_t code = (uint32_t)~cur;
+            const uint32_t first = code >> 3, count = (code & 7u) + 1u;
+            for (uint32_t k = 0; k < count; k++) {
+                const TriRec T = load_tri(sc.tris, first + k);
+                float t, u, v, det;
+                if (!tri_hit(r, T, t, u, v, det)) continue;
+                if (!(t > TMIN && t < TMAX)) continue;
+                if (ANY_HIT) {
+                    if (det > 0.0f) { occluded = true; return; }      // front face: counter-clockwise seen from the origin
+                } else if (t < best_t || (t == best_t && T.prim < best_prim)) {
+                    best_t = t; best_u = u; best_v = v; best_pos = first + k; best_prim = T.prim;
+                }
+            }
+            if (st.sp == 0) return;
+            cur = st.pop();
+        }
+    }
+}
+
+// closest hit over the radiance queue of this depth
+__global__ __launch_bounds__(FOVPT_BLOCK) void k_trace(SceneView sc, PathState ps, const uint32_t* __restrict__ queue,
+                                                       Counters* __restrict__ cnt, int depth, int* __restrict__ spill)
+{
+    __shared__ int s_stack[FOVPT_STACK_LDS * FOVPT_BLOCK];
+    const uint32_t n = cnt->q[depth];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        atomicAdd(&cnt->stat_radiance, (unsigned long long)n);
+        if (depth == 0) atomicAdd(&cnt->stat_paths, (unsigned long long)n);
+    }
+    Stack st;
+    st.lds = s_stack + threadIdx.x;
+    st.stride = gridDim.x * FOVPT_BLOCK;
+    st.spill = spill + blockIdx.x * FOVPT_BLOCK + threadIdx.x;
+    for (uint32_t i = blockIdx.x * FOVPT_BLOCK + threadIdx.x; i < n; i += gridDim.x * FOVPT_BLOCK) {
+        const uint32_t slot = queue[i];
+        RayT r;
+        ray_setup(r, ps.ray_o[slot], ps.ray_d[slot]);
+        float bt = INFINITY, bu = 0.f, bv = 0.f;
+        uint32_t bpos = 0xffffffffu, bprim = 0xffffffffu;
+        bool occ = false;
+        traverse<false>(sc, r, st, bt, bu, bv, bpos, bprim, occ);
+        ps.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(bpos));
+    }
+}
+
+// occlusion over the shadow queue of this depth; applies the deferred NEE contribution
+__global__ __launch_bounds__(FOVPT_BLOCK) void k_shadow(SceneView sc, PathState ps, ShadowQueue sq, Counters* __restrict__ cnt,
+                                                        int depth, int* __restrict__ spill)
+{
+    __shared__ int s_stack[FOVPT_STACK_LDS * FOVPT_BLOCK];
+    const uint32_t n = cnt->sq[depth];
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->stat_shadow, (unsigned long long)n);
+    Stack st;
+    st.lds = s_stack + threadIdx.x;
+    st.stride = gridDim.x * FOVPT_BLOCK;
+    st.spill = spill + blockIdx.x * FOVPT_BLOCK + threadIdx.x;
+    for (uint32_t i = blockIdx.x * FOVPT_BLOCK + threadIdx.x; i < n; i += gridDim.x * FOVPT_BLOCK) {
+        const float4 o = sq.o[i], d = sq.d[i];
+        RayT r;
+        ray_setup(r, o, d);
+        float bt = INFINITY, bu, bv;
+        uint32_t bpos, bprim = 0;
+        bool occ = false;
+        traverse<true>(sc, r, st, bt, bu, bv, bpos, bprim, occ);
+        const float4 val = occ ? sq.val_occ[i] : sq.val_vis[i];
+        const uint32_t slot = __float_as_uint(o.w);
+        const uint32_t target = __float_as_uint(d.w);
+        float4* acc = target == 0u ? ps.direct : (target == 1u ? ps.indirect : ps.alpha);
+        float4 a = acc[slot];
+        a.x += val.x; a.y += val.y; a.z += val.z;
+        acc[slot] = a;
+    }
+}
+
+// ---- shade -------------------------------------------------------------------------------
+#define FLAG_DONE 1u
+#define FLAG_SECONDARY 2u
+
+__device__ inline float4 tex_texel(const TexDev& T, int x, int y)
+{
+    x %= T.w; if (x < 0) x += T.w;
+    y %= T.h; if (y < 0) y += T.h;
+    const uint32_t p = T.px[(size_t)y * T.w + x];
+    return make_float4((float)(p & 255u) / 255.0f, (float)((p >> 8) & 255u) / 255.0f, (float)((p >> 16) & 255u) / 255.0f, (float)(p >> 24) / 255.0f);
+}
+// bilinear, wrap, normalized coordinates (the fp32 contract standing in for tex2D<float4>, :664)
+__device__ inline float4 tex2d(const TexDev& T, float u, float v)
+{
+    const float x = u * (float)T.w - 0.5f, y = v * (float)T.h - 0.5f;
+    const float fx0 = floorf(x), fy0 = floorf(y);
+    const float fx = x - fx0, fy = y - fy0;
+    const int x0 = (int)fmaxf(-1.0e9f, fminf(1.0e9f, fx0)), y0 = (int)fmaxf(-1.0e9f, fminf(1.0e9f, fy0));
+    const float4 c00 = tex_texel(T, x0, y0), c10 = tex_texel(T, x0 + 1, y0), c01 = tex_texel(T, x0, y0 + 1), c11 = tex_texel(T, x0 + 1, y0 + 1);
+    const float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy), w01 = (1.0f - fx) * fy, w11 = fx * fy;
+    return make_float4(w00 * c00.x + w10 * c10.x + w01 * c01.x + w11 * c11.x,
+                       w00 * c00.y + w10 * c10.y + w01 * c01.y + w11 * c11.y,
+                       w00 * c00.z + w10 * c10.z + w01 * c01.z + w11 * c11.z,
+                       w00 * c00.w + w10 * c10.w + w01 * c01.w + w11 * c11.w);
+}
+
+__device__ inline void acc_add(float4* acc, uint32_t slot, const V3& v)
+{
+    float4 a = acc[slot];
+    a.x += v.x; a.y += v.y; a.z += v.z;
+    acc[slot] = a;
+}
+
+__global__ __launch_bounds__(FOVPT_BLOCK) void k_shade(const FrameDev fd, SceneView sc, PathState ps,
+                                                       const uint32_t* __restrict__ queue_in, uint32_t* __restrict__ queue_out,
+                                                       ShadowQueue sq, Counters* __restrict__ cnt, int depth_iter)
+{
+    const uint32_t n = cnt->q[depth_iter];
+    const uint32_t nround = (n + FOVPT_BLOCK - 1) / FOVPT_BLOCK * FOVPT_BLOCK;
+    for (uint32_t i = blockIdx.x * FOVPT_BLOCK + threadIdx.x; i < nround; i += gridDim.x * FOVPT_BLOCK) {
+        bool want_shadow = false, want_next = false;
+        uint32_t slot = 0;
+        float4 sh_o, sh_d, sh_vis, sh_occ;
+        sh_o = sh_d = sh_vis = sh_occ = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n) {
+            slot = queue_in[i];
+            const float4 hit = ps.hit[slot];
+            const uint32_t tpos = __float_as_uint(hit.w);
+            uint4 rs = ps.rng[slot];
+            uint32_t flags = rs.z & 0xffu;
+            int depth = (int)(rs.z >> 8);
+            if (tpos == 0xffffffffu) {
+                // __miss__radiance :253-282: DONE; nothing is added for this segment (:515 breaks first)
+                flags |= FLAG_DONE;
+            } else {
+                const float4 o4 = ps.ray_o[slot], d4 = ps.ray_d[slot];
+                const V3 ray_o = v3(o4), ray_dir = v3(d4);
+                const TriRec T = load_tri(sc.tris, tpos);
+                const MeshDev M = sc.meshes[T.mesh];
+                const Mat& mat = M.material;
+                const V3 e1 = v3(T.e1x, T.e1y, T.e1z), e2 = v3(T.e2x, T.e2y, T.e2z);
+                const V3 N_0 = normalize(cross(e1, e2));                                   // :632
+                const V3 wo = neg(ray_dir);
+                const V3 N = N_0 * copysignf(1.0f, dot(wo, N_0));                          // faceforward :634
+                const V3 P = ray_o + hit.x * ray_dir;                                      // :638
+                const bool catcher = (mat.flags & FOVPT_MATERIAL_FLAG_SHADOW_CATCHER) != 0;
+                if (catcher && (flags & FLAG_SECONDARY)) {
+                    // :646-651: pass straight through, depth unchanged after the loop's ++depth;
+                    // the loop adds prd.radiance == 0 to direct/indirect, which changes nothing
+                    ps.ray_o[slot] = f4(P, 0.f);
+                    want_next = true;
+                } else if (depth >= fd.max_depth) {
+                    // the reference's discarded last segment (:515).  It is only traced here when the
+                    // scene holds a shadow catcher; a catcher hit is always a pass-through at this
+                    // depth (SECONDARY is set), so this is a plain hit whose one lasting effect is :689
+                    ps.alpha[slot] = make_float4(1.f, 1.f, 1.f, 0.f);
+                    flags |= FLAG_DONE;
+                } else {
+                    float4 t4 = ps.thr[slot];
+                    V3 thr = v3(t4);
+                    float rayEta = t4.w;
+                    Rng rng; rng.s1 = rs.x; rng.s2 = rs.y;
+                    V3 albedo = v3(mat.color);
+                    if (M.texture_id >= 0 && M.has_texcoord) {                             // :655-670
+                        const float2* tc = sc.tri_tc + (size_t)T.prim * 3;
+                        const float2 t0 = tc[0], t1 = tc[1], t2 = tc[2];
+                        const float w0 = 1.f - hit.y - hit.z;
+                        const float tcx = (w0 * t0.x + hit.y * t1.x) + hit.z * t2.x;
+                        const float tcy = (w0 * t0.y + hit.y * t1.y) + hit.z * t2.y;
+                        albedo = v3(tex2d(sc.textures[M.texture_id], tcx, tcy));
+                    }
+                    float outEta;
+                    if (rayEta == 1.0f)                                                    // :673-683
+                        outEta = (mat.eta == 0.0f) ? 2.0f / (1.0f - sqrtf(0.08f * mat.specular)) - 1.0f : mat.eta;
+                    else
+                        outEta = 1.0f;
+                    // ---- SampleLights / SampleShadow :303-387 with the occlusion test deferred
+                    V3 wi, skyColor; float skyPdf;
+                    probe_sample(fd.probe, wi, skyColor, skyPdf, rng);
+                    V3 sum_hit = v3(0.0f);        // value of `sum` on the branch that evaluates the BSDF
+                    {
+                        const float bsdfPdf = bsdf_pdf(mat, rayEta, outEta, N, wo, wi);
+                        const V3 f = bsdf_eval(mat, albedo, rayEta, outEta, N, wo, wi);
+                        if (bsdfPdf > 0.0f) {
+                            const float weight = 0.5f * skyPdf / (0.5f * bsdfPdf + 0.5f * skyPdf);
+                            if (weight > 0.0f) {
+                                const V3 val = div_vs(weight * skyColor * f * fabsf(dot(wi, N)), skyPdf) * (1.0f / 1.f);
+                                sum_hit = sum_hit + val;
+                            }
+                        }
+                    }
+                    const V3 sum_zero = v3(0.0f);
+                    V3 rad_vis, rad_occ;          // prd.radiance after this hit if the shadow ray is un/occluded
+                    V3 alpha_vis = v3(0.f), alpha_occ = v3(0.f);
+                    bool alpha_set_one = false;
+                    if (!catcher) {                                                        // :686-690
+                        rad_vis = v3(0.f) + thr * sum_hit;
+                        rad_occ = v3(0.f) + thr * sum_zero;
+                        alpha_set_one = true;
+                    } else {                                                               // :691-694 SampleShadow
+                        rad_vis = v3(0.f); rad_occ = v3(0.f);
+                        alpha_vis = thr * sum_zero;
+                        alpha_occ = thr * sum_hit;
+                    }
+                    if ((flags & FLAG_SECONDARY) == 0) {                                   // :696-698
+                        rad_vis = rad_vis + v3(mat.emission);
+                        rad_occ = rad_occ + v3(mat.emission);
+                    }
+                    V3 bu, bv;
+                    basis_from_vector(N, bu, bv);
+                    V3 bsdfDir = v3(0.f);
+                    const float bsdfPdf = bsdf_sample(mat, rayEta, outEta, bu, bv, N, wo, bsdfDir, rng);   // :706
+                    if (alpha_set_one) ps.alpha[slot] = make_float4(1.f, 1.f, 1.f, 0.f);  // :689 (kept even when DONE)
+                    const bool same = rad_vis.x == rad_occ.x && rad_vis.y == rad_occ.y && rad_vis.z == rad_occ.z
+                                   && alpha_vis.x == alpha_occ.x && alpha_vis.y == alpha_occ.y && alpha_vis.z == alpha_occ.z;
+                    if (catcher) {
+                        // alpha += thr * shadowSample happens regardless of what follows (:693)
+                        if (same) acc_add(ps.alpha, slot, alpha_occ);
+                        else {
+                            want_shadow = true;
+                            sh_o = f4(P, __uint_as_float(slot)); sh_d = f4(wi, __uint_as_float(2u));
+                            sh_vis = f4(alpha_vis, 0.f); sh_occ = f4(alpha_occ, 0.f);
+                        }
+                    }
+                    if (bsdfPdf <= 0.0f) {                                                 // :708-711
+                        flags |= FLAG_DONE;       // radiance of this hit is dropped by the break at :515
+                    } else {
+                        // the segment counts: direct (depth 0) or indirect gets prd.radiance (:522-527)
+                        float4* acc = depth == 0 ? ps.direct : ps.indirect;
+                        if (!catcher) {
+                            if (same) acc_add(acc, slot, rad_occ);
+                            else {
+                                want_shadow = true;
+                                sh_o = f4(P, __uint_as_float(slot)); sh_d = f4(wi, __uint_as_float(depth == 0 ? 0u : 1u));
+                                sh_vis = f4(rad_vis, 0.f); sh_occ = f4(rad_occ, 0.f);
+                            }
+                        } else {
+                            acc_add(acc, slot, rad_occ);
+                        }
+                        const V3 f = bsdf_eval(mat, albedo, rayEta, outEta, N, wo, bsdfDir);   // :714
+                        if (dot(bsdfDir, N) <= 0.0f) rayEta = outEta;                      // :717-721
+                        thr = thr * div_vs(f * fabsf(dot(N, bsdfDir)), bsdfPdf);           // :724
+                        flags |= FLAG_SECONDARY;
+                        depth += 1;                                                        // :529
+                        // The reference traces once more at depth == max_depth and throws the result
+                        // away (:515).  Without a shadow catcher in the scene that segment cannot
+                        // change anything (alpha is already 1), so it is not traced.
+                        if (depth < fd.max_depth || sc.any_catcher) {
+                            ps.ray_o[slot] = f4(P, 0.f);
+                            ps.ray_d[slot] = f4(bsdfDir, 0.f);
+                            ps.thr[slot] = f4(thr, rayEta);
+                            want_next = true;
+                        }
+                    }
+                    rs.x = rng.s1; rs.y = rng.s2;
+                }
+            }
+            rs.z = flags | ((uint32_t)depth << 8);
+            ps.rng[slot] = rs;
+        }
+        // ---- wavefront-ballot compaction into the next queues
+        const uint32_t spos = wave_append(&cnt->sq[depth_iter], want_shadow);
+        if (want_shadow) { sq.o[spos] = sh_o; sq.d[spos] = sh_d; sq.val_vis[spos] = sh_vis; sq.val_occ[spos] = sh_occ; }
+        const uint32_t qpos = wave_append(&cnt->q[depth_iter + 1], want_next);
+        if (want_next) queue_out[qpos] = slot;
+    }
+}
+
+// ---- resolve -----------------------------------------------------------------------------
+__device__ inline V3 reinhard(const V3& color, float white)                    // :126-131
+{
+    const float luminance = 0.2126f * color.x + 0.7152f * color.y + 0.0722f * color.z;
+    return div_vs(color * 1.0f, 1.0f + luminance / white);
+}
+__device__ inline float srgb1(float c)                                          // cuda/helpers.h:35-43
+{
+    const float invGamma = 1.0f / 2.4f;
+    const float powed = fovpt_dm_powf(c, invGamma);
+    return c < 0.0031308f ? 12.92f * c : 1.055f * powed - 0.055f;
+}
+__device__ inline uint32_t quant8(float x)                                      // cuda/helpers.h:50-55
+{
+    x = clampf(x, 0.0f, 1.0f);
+    return min((uint32_t)(x * 256.0f), 255u);
+}
+__device__ inline uint32_t make_color(const V3& c)                              // cuda/helpers.h:57-62
+{
+    const V3 cc = clamp3(c, 0.0f, 1.0f);
+    return quant8(srgb1(cc.x)) | (quant8(srgb1(cc.y)) << 8) | (quant8(srgb1(cc.z)) << 16) | (255u << 24);
+}
+
+// candidate launch-index range along one axis for pixel coordinate x (resolve)
+__device__ inline void writer_range(uint32_t x, uint32_t frame_dim, uint32_t factor, int fill, uint32_t off, uint32_t grid, long long& lo, long long& hi)
+{
+    const long long r = (long long)x - (long long)(int32_t)off;
+    const long long f = factor ? factor : 1;
+    const long long s1 = fill - 1;
+    auto floordiv = [](long long a, long long b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+    long long a = floordiv(r - s1 + f - 1, f);      // ceil((r - s1) / f)
+    if (a < 0) a = 0;
+    long long b;
+    if (x + 1 == frame_dim) b = (long long)grid - 1;  // clamp at :554 folds everything beyond the edge onto it
+    else { b = r < 0 ? -1 : r / f; if (b > (long long)grid - 1) b = (long long)grid - 1; }
+    lo = a; hi = b;
+}
+
+__global__ __launch_bounds__(FOVPT_BLOCK) void k_resolve(const FrameDev fd, PathState ps)
+{
+    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= (uint32_t)fd.w || y >= (uint32_t)fd.h) return;
+    const uint32_t image_index = y * (uint32_t)fd.w + x;
+    for (int p = fd.npass - 1; p >= 0; p--) {
+        const PassDev& P = fd.pass[p];
+        if (P.fill <= 0) continue;
+        long long xa, xb, ya, yb;
+        writer_range(x, (uint32_t)fd.w, P.fx, P.fill, P.offx, P.gw, xa, xb);
+        writer_range(y, (uint32_t)fd.h, P.fy, P.fill, P.offy, P.gh, ya, yb);
+        for (long long ly = yb; ly >= ya; ly--) {
+            for (long long lx = xb; lx >= xa; lx--) {
+                uint32_t ix, iy;
+                if (!ring_alive(fd, P, (uint32_t)lx, (uint32_t)ly, ix, iy)) continue;
+                // last writer found
+                if (!launch_owned(fd, p, (uint32_t)lx, (uint32_t)ly)) {
+                    fd.accum[image_index] = fovpt_float4{0.f, 0.f, 0.f, 0.f};    // another rank's pixel: keep the sum-gather exact
+                    fd.frame[image_index] = 0u;
+                    return;
+                }
+                const uint32_t li = (uint32_t)ly * P.gw + (uint32_t)lx;
+                const uint32_t s0 = P.slot_base + li * P.spp;
+                V3 result = v3(0.0f), alpha = v3(0.0f);
+                for (uint32_t s = 0; s < P.spp; s++) {                                     // :536-537, in sample order
+                    const V3 d = v3(ps.direct[s0 + s]), in = v3(ps.indirect[s0 + s]);
+                    result = result + (d + in);
+                    alpha = alpha + v3(ps.alpha[s0 + s]);
+                }
+                const float sppf = (float)P.spp;
+                { const float inv = 1.0f / sppf; alpha = alpha * inv; }                    // :543
+                const V3 backplate = v3(ps.backplate[P.launch_base + li]);
+                const V3 color = (backplate * sppf) * sub_sv(1.0f, alpha) + result;        // :558
+                V3 accum_color = div_vs(color, sppf);                                      // :560
+                if (fd.accumulate && P.subframe > 0 && !P.redraw) {
+                    // PT_sv4_vmv2/deviceProgram.cu:545-553
+                    accum_color = clamp3(accum_color, 0.0f, 10.0f);
+                    const float alpha_value = 1.0f / (float)(P.subframe + 1);
+                    const fovpt_float4 pv = fd.accum[image_index];
+                    accum_color = lerp3(v3(pv.x, pv.y, pv.z), accum_color, alpha_value);
+                }
+                fd.accum[image_index] = fovpt_float4{accum_color.x, accum_color.y, accum_color.z, 1.0f};   // :582
+                const V3 exposed = accum_color * 16.0f;                                    // :586
+                fd.frame[image_index] = make_color(reinhard(exposed, 1.0f));               // :597
+                return;
+            }
+        }
+    }
+    if (fd.world > 1) {   // nobody writes this pixel: contribute zero to the gather, rank 0 keeps the old value
+        if (fd.rank != 0) { fd.accum[image_index] = fovpt_float4{0.f, 0.f, 0.f, 0.f}; fd.frame[image_index] = 0u; }
+    }
+}
+
+// ---- device self-test --------------------------------------------------------------------
+__global__ void k_math(int op, const float* a, const float* b, float* out, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float r = 0.f;
+    switch (op) {
+    case FOVPT_OP_SIN: r = fovpt_dm_sinf(a[i]); break;
+    case FOVPT_OP_COS: r = fovpt_dm_cosf(a[i]); break;
+    case FOVPT_OP_ACOS: r = fovpt_dm_acosf(a[i]); break;
+    case FOVPT_OP_ATAN2: r = fovpt_dm_atan2f(a[i], b[i]); break;
+    case FOVPT_OP_LOG: r = fovpt_dm_logf(a[i]); break;
+    case FOVPT_OP_POW: r = fovpt_dm_powf(a[i], b[i]); break;
+    case FOVPT_OP_SQRT: r = sqrtf(a[i]); break;
+    case FOVPT_OP_DIV: r = a[i] / b[i]; break;
+    case FOVPT_OP_RSQRTD: r = (float)(1.0 / (double)sqrtf(a[i])); break;
+    }
+    out[i] = r;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+void fovpt_launch_generate(hipStream_t st, const FrameDev& fd, PathState ps, uint32_t* queue0, Counters* cnt, uint32_t total_slots, int grid)
+{
+    hipLaunchKernelGGL(k_generate, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, ps, queue0, cnt, total_slots);
+}
+void fovpt_launch_trace(hipStream_t st, SceneView sc, PathState ps, const uint32_t* queue, Counters* cnt, int depth, int* spill, int grid)
+{
+    hipLaunchKernelGGL(k_trace, dim3(grid), dim3(FOVPT_BLOCK), 0, st, sc, ps, queue, cnt, depth, spill);
+}
+void fovpt_launch_shade(hipStream_t st, const FrameDev& fd, SceneView sc, PathState ps, const uint32_t* queue_in, uint32_t* queue_out,
+                        ShadowQueue sq, Counters* cnt, int depth, int grid)
+{
+    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, sc, ps, queue_in, queue_out, sq, cnt, depth);
+}
+void fovpt_launch_shadow(hipStream_t st, SceneView sc, PathState ps, ShadowQueue sq, Counters* cnt, int depth, int* spill, int grid)
+{
+    hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(FOVPT_BLOCK), 0, st, sc, ps, sq, cnt, depth, spill);
+}
+void fovpt_launch_resolve(hipStream_t st, const FrameDev& fd, PathState ps)
+{
+    dim3 grid((fd.w + 63) / 64, (fd.h + 3) / 4);
+    hipLaunchKernelGGL(k_resolve, grid, dim3(FOVPT_BLOCK), 0, st, fd, ps);
+}
+void fovpt_launch_math(hipStream_t st, int op, const float* a, const float* b, float* out, size_t n)
+{
+    hipLaunchKernelGGL(k_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, op, a, b, out, n);
+}

@@ -1,0 +1,83 @@
+"""Loader for libfovpt.so (the HIP C-ABI library, include/fovpt.h).
+
+There is no CPU fallback: if the library is missing or a call fails, an exception is raised.
+"""
+import ctypes as C
+import os
+import subprocess
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libfovpt.so")
+
+EXPORTS = [
+    "fovpt_create", "fovpt_destroy", "fovpt_last_error", "fovpt_set_scene", "fovpt_set_probe",
+    "fovpt_resize", "fovpt_get_config", "fovpt_set_config", "fovpt_launch", "fovpt_render",
+    "fovpt_synchronize", "fovpt_download", "fovpt_get_stats", "fovpt_reset_stats", "fovpt_stream",
+    "fovpt_probe_build_cdf", "fovpt_camera_uvw", "fovpt_debug_math",
+]
+
+
+class FovptError(RuntimeError):
+    """The std::runtime_error of the reference (sutil::Exception, sutil/Exception.h:245)."""
+
+    def __init__(self, code, msg):
+        super().__init__("libfovpt error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build(force=False):
+    """Compile libfovpt.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+    args = ["make", "-C", CSRC, "-s", "-j4"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return SO_PATH
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise FovptError(-100, "%s is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)" % SO_PATH)
+    L = C.CDLL(SO_PATH)
+    vp, i32, u32, u64, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_size_t
+    L.fovpt_create.argtypes = [C.POINTER(vp), i32]
+    L.fovpt_destroy.argtypes = [vp]
+    L.fovpt_destroy.restype = None
+    L.fovpt_last_error.argtypes = [vp]
+    L.fovpt_last_error.restype = C.c_char_p
+    L.fovpt_set_scene.argtypes = [vp, vp, i32, vp, i32, C.POINTER(u64)]
+    L.fovpt_set_probe.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(abi.Probe)]
+    L.fovpt_resize.argtypes = [vp, i32, i32, C.POINTER(abi.FramePtrs)]
+    L.fovpt_get_config.argtypes = [vp, C.POINTER(abi.Config)]
+    L.fovpt_set_config.argtypes = [vp, C.POINTER(abi.Config)]
+    L.fovpt_launch.argtypes = [vp, C.POINTER(abi.LaunchParams), u32, u32]
+    L.fovpt_render.argtypes = [vp, C.POINTER(abi.LaunchParams)]
+    L.fovpt_synchronize.argtypes = [vp]
+    L.fovpt_download.argtypes = [vp, vp, vp, sz]
+    L.fovpt_get_stats.argtypes = [vp, C.POINTER(abi.Stats)]
+    L.fovpt_reset_stats.argtypes = [vp]
+    L.fovpt_stream.argtypes = [vp]
+    L.fovpt_stream.restype = vp
+    L.fovpt_probe_build_cdf.argtypes = [i32, i32, vp, vp, vp, vp, vp]
+    L.fovpt_camera_uvw.argtypes = [C.POINTER(abi.Float3), C.POINTER(abi.Float3), C.POINTER(abi.Float3),
+                                   C.c_float, C.c_float, C.POINTER(abi.Float3), C.POINTER(abi.Float3), C.POINTER(abi.Float3)]
+    L.fovpt_debug_math.argtypes = [vp, i32, vp, vp, vp, sz]
+    for name in EXPORTS:
+        if name not in ("fovpt_destroy", "fovpt_last_error", "fovpt_stream"):
+            getattr(L, name).restype = i32
+    _lib = L
+    return L
+
+
+def check(ctx, rc):
+    if rc != 0:
+        msg = load().fovpt_last_error(ctx)
+        raise FovptError(rc, msg.decode("utf-8", "replace") if msg else "")

@@ -1,0 +1,47 @@
+"""Ad-hoc timing of the headline workload (C3) on one GPU; prints stats.  Not the bench contract."""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from fovpathtracing_optixcodelatest_amd import abi, renderer, scenes
+
+W, H = 1920, 1080
+ntri = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+t = time.time(); model = scenes.atrium(ntri); print("scene", model.num_triangles, "tris", round(time.time() - t, 2), "s")
+t = time.time(); r = renderer.SampleRenderer(model); print("set_scene", round(time.time() - t, 2), "s")
+r.resize((W, H))
+cam = scenes.ATRIUM_CAMERA
+r.setCamera(renderer.Camera(cam["eye"], cam["lookat"], cam["up"], cam["fovy"], W / H))
+t = time.time(); r.setProbe(renderer.ProbeData(scenes.ambient_probe(W, H, 2.5)).BuildCDF()); print("probe", round(time.time() - t, 2), "s")
+cfg = abi.Config.reference_default()
+cfg.r_inner, cfg.r_outer = 148, 482
+cfg.spp_periphery, cfg.spp_middle, cfg.spp_fovea = 1, 2, 8
+for profile in (0, 1):
+    cfg.profile = profile
+    r.config = cfg
+    r.launchParams.frame.c.x, r.launchParams.frame.c.y = W // 2, H // 2
+    for _ in range(3):
+        r.launchParams.frame.subframe_index = 0
+        r.render()
+    r.reset_stats()
+    t = time.time()
+    for _ in range(frames):
+        r.launchParams.frame.subframe_index = 0
+        r.render_async()
+    r.synchronize()
+    dt = (time.time() - t) / frames
+    s = r.stats()
+    rays = (s.radiance_rays + s.shadow_rays) / frames
+    print("profile", profile, "ms/frame %.3f" % (dt * 1e3), "rays/frame %.0f" % rays, "Mray/s %.1f" % (rays / dt / 1e6),
+          "paths", s.paths // frames, "rad", s.radiance_rays // frames, "shadow", s.shadow_rays // frames)
+    if profile:
+        print("  per-frame ms: gen %.3f trace %.3f shade %.3f shadow %.3f resolve %.3f" % tuple(
+            x / frames for x in (s.ms_generate, s.ms_trace, s.ms_shade, s.ms_shadow, s.ms_resolve)))
+print("bvh nodes", s.num_bvh_nodes, "depth", s.bvh_max_depth, "build ms %.2f" % s.ms_bvh_build, "bvh MB %.1f" % (s.bvh_bytes / 1e6), "tri MB %.1f" % (s.tri_bytes / 1e6))
+acc = r.downloadAccum()
+print("accum mean", acc[..., :3].mean(axis=(0, 1)), "max", acc[..., :3].max(), "finite", np.isfinite(acc).all())
+px = r.downloadPixels()
+img = np.stack([(px >> s_) & 255 for s_ in (0, 8, 16)], -1).astype(np.uint8)
+os.makedirs("gpurun_out", exist_ok=True)
+with open("gpurun_out/c3.ppm", "wb") as f:
+    f.write(b"P6 %d %d 255\n" % (W, H) + img[::-1].tobytes())
