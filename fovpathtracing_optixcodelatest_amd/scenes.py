@@ -331,3 +331,20 @@ def pack_model(model: Model):
         td[k].width = px.shape[1]
         td[k].height = px.shape[0]
     return md, len(model.meshes), td, len(model.textures), keep
+
+
+def box_mesh(pos, extend, material) -> TriangleMesh:
+    """addBox (PT_sv5_/Model.cpp:219-291): 12 triangles over 36 unshared vertices, in the reference's
+    face and winding order (front, back, left, right, top, bottom)."""
+    sx = (-1, 1, 1, -1, -1, 1, 1, -1)
+    sy = (-1, -1, 1, 1, -1, -1, 1, 1)
+    sz = (1, 1, 1, 1, -1, -1, -1, -1)
+    P = [(np.float32(sx[k]) * np.float32(extend[0]) + np.float32(pos[0]),
+          np.float32(sy[k]) * np.float32(extend[1]) + np.float32(pos[1]),
+          np.float32(sz[k]) * np.float32(extend[2]) + np.float32(pos[2])) for k in range(8)]
+    A, B, C_, D, E, F, G, H = range(8)
+    tri = [(A, B, C_), (A, C_, D), (E, H, G), (E, G, F), (E, A, D), (E, D, H),
+           (B, F, G), (B, G, C_), (D, C_, G), (D, G, H), (E, A, B), (E, B, F)]
+    v = np.array([P[i] for t in tri for i in t], np.float32)
+    idx = np.arange(36, dtype=np.uint32).reshape(12, 3)
+    return TriangleMesh(v, idx, material, np.zeros((36, 2), np.float32), -1)

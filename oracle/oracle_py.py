@@ -164,3 +164,71 @@ def math_op(op, a, b=None):
     out = np.empty_like(a)
     lib().orc_math(op, a.size, _p(a), _p(bb), _p(out))
     return out
+
+
+# ---- unit-level entry points -----------------------------------------------------------------
+def tea4(a, b):
+    return int(lib().orc_tea4(a & 0xFFFFFFFF, b & 0xFFFFFFFF))
+
+
+def lcg_stream(seed, n):
+    u = np.empty(n, np.uint32)
+    f = np.empty(n, np.float32)
+    lib().orc_lcg_stream(C.c_uint32(seed & 0xFFFFFFFF), n, _p(u), _p(f))
+    return u, f
+
+
+def random_stream(seed, n):
+    u = np.empty(n, np.uint32)
+    f = np.empty(n, np.float32)
+    s = seed if seed < 0x80000000 else seed - (1 << 32)
+    lib().orc_random_stream(C.c_int(s), n, _p(u), _p(f))
+    return u, f
+
+
+def probe_sample(probe: "HostProbe", seed, n):
+    d = np.empty((n, 3), np.float32)
+    c = np.empty((n, 3), np.float32)
+    p = np.empty(n, np.float32)
+    lib().orc_probe_sample(C.byref(probe.struct), C.c_int(seed), n, _p(d), _p(c), _p(p))
+    return d, c, p
+
+
+def probe_dir_to_uv(dirs):
+    d = np.ascontiguousarray(dirs, np.float32)
+    uv = np.empty((d.shape[0], 2), np.float32)
+    lib().orc_probe_dir_to_uv(d.shape[0], _p(d), _p(uv))
+    return uv
+
+
+def bsdf_table(material, N, view, albedo, etaI, etaO, seeds):
+    n = len(seeds)
+    N, view, albedo = (np.ascontiguousarray(x, np.float32) for x in (N, view, albedo))
+    etaI, etaO = np.ascontiguousarray(etaI, np.float32), np.ascontiguousarray(etaO, np.float32)
+    seeds = np.ascontiguousarray(seeds, np.int32)
+    light = np.empty((n, 3), np.float32)
+    pdf = np.empty(n, np.float32)
+    typ = np.empty(n, np.int32)
+    ev = np.empty((n, 3), np.float32)
+    pdf2 = np.empty(n, np.float32)
+    rng = np.empty((n, 2), np.uint32)
+    lib().orc_bsdf_table(C.byref(material), n, _p(N), _p(view), _p(albedo), _p(etaI), _p(etaO), _p(seeds),
+                         _p(light), _p(pdf), _p(typ), _p(ev), _p(pdf2), _p(rng))
+    return dict(light=light, pdf=pdf, type=typ, eval=ev, pdf_again=pdf2, rng_after=rng)
+
+
+def make_color(rgb):
+    rgb = np.ascontiguousarray(rgb, np.float32)
+    out = np.empty(rgb.shape[0], np.uint32)
+    lib().orc_make_color(rgb.shape[0], _p(rgb), _p(out))
+    return out
+
+
+def tex2d(texture_u32, uv):
+    px = np.ascontiguousarray(texture_u32, np.uint32)
+    td = abi.TextureDesc()
+    td.pixel, td.width, td.height = px.ctypes.data, px.shape[1], px.shape[0]
+    uv = np.ascontiguousarray(uv, np.float32)
+    out = np.empty((uv.shape[0], 4), np.float32)
+    lib().orc_tex2d(C.byref(td), uv.shape[0], _p(uv), _p(out))
+    return out
