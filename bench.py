@@ -43,6 +43,19 @@ def algorithmic_bytes_per_ray(num_tris, kind):
     return b_queue + b_trav + b_leaf + b_out
 
 
+def host_cpu_share():
+    """CPU threads this job may actually use: the cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+            if quota != "max":
+                n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,7 +218,7 @@ def main():
         S = orc.OracleScene(model)
         hp = orc.HostProbe(probe_data, cdf=(probe.pdfValuesX, probe.cdfValuesX, probe.pdfValuesY, probe.cdfValuesY))
         F = orc.OracleFrame(W, H, hp, cam)
-        cores = os.cpu_count() or 1
+        cores = host_cpu_share()
         ocfg = cfg.copy()
         ocfg.rank, ocfg.world = 0, 1
         frames_done, rays_done = 0, 0
