@@ -147,9 +147,11 @@ int ensure_state(fovpt_ctx* c, size_t slots, size_t launches)
     HIPCHK(c, c->s_hit.reserve(slots * v)); HIPCHK(c, c->s_direct.reserve(slots * v));
     HIPCHK(c, c->s_indirect.reserve(slots * v)); HIPCHK(c, c->s_alpha.reserve(slots * v));
     HIPCHK(c, c->s_backplate.reserve(launches * v));
-    HIPCHK(c, c->q_a.reserve(slots * 4)); HIPCHK(c, c->q_b.reserve(slots * 4));
-    HIPCHK(c, c->sq_o.reserve(slots * v)); HIPCHK(c, c->sq_d.reserve(slots * v));
-    HIPCHK(c, c->sq_vis.reserve(slots * v)); HIPCHK(c, c->sq_occ.reserve(slots * v));
+    // sharded queues: FOVPT_SHARDS regions of `slots` entries each (memory is laid out for 288 GB)
+    const size_t qn = slots * FOVPT_SHARDS;
+    HIPCHK(c, c->q_a.reserve(qn * 4)); HIPCHK(c, c->q_b.reserve(qn * 4));
+    HIPCHK(c, c->sq_o.reserve(qn * v)); HIPCHK(c, c->sq_d.reserve(qn * v));
+    HIPCHK(c, c->sq_vis.reserve(qn * v)); HIPCHK(c, c->sq_occ.reserve(qn * v));
     if (!c->counters.p) {
         HIPCHK(c, c->counters.reserve(sizeof(Counters)));
         HIPCHK(c, hipMemsetAsync(c->counters.p, 0, sizeof(Counters), c->stream));
@@ -181,7 +183,7 @@ int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passe
         launches += (uint64_t)P.gw * P.gh;
         fd.pass[p] = P;
     }
-    if (slots >= (1ull << 31)) return fail(c, FOVPT_E_INVALID, "launch too large: %llu sample slots", (unsigned long long)slots);
+    if (slots * FOVPT_SHARDS >= (1ull << 32)) return fail(c, FOVPT_E_INVALID, "launch too large: %llu sample slots", (unsigned long long)slots);
     fd.npass = npass;
     fd.w = lp->frame.size.x; fd.h = lp->frame.size.y;
     fd.cx = lp->frame.c.x; fd.cy = lp->frame.c.y;
@@ -219,15 +221,18 @@ int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passe
 
     HIPCHK(c, hipMemsetAsync(cnt, 0, offsetof(Counters, stat_radiance), st));
     const int grid = c->grid;
-    { Timed t(c, 0); fovpt_launch_generate(st, fd, ps, qa, cnt, (uint32_t)slots, grid); }
+    const uint32_t cap = (uint32_t)slots;              // shard capacity: any shard may hold everything
+    { Timed t(c, 0); fovpt_launch_generate(st, fd, ps, qa, cap, cnt, (uint32_t)slots, grid); }
     // iterations: depth 0 .. max_depth-1, plus the reference's discarded segment and shadow-catcher
     // pass-throughs (which do not advance depth) when the scene holds a catcher
     int iters = c->cfg.max_depth + (c->any_catcher ? 1 + 24 : 0);
     if (iters > FOVPT_MAX_ITERS) iters = FOVPT_MAX_ITERS;
+    // launch 0 traces the camera rays; launch it+1 traces the shadow rays of bounce `it` together
+    // with the radiance rays of bounce `it+1`
+    { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qa, sq, cap, cnt, 0, -1, (int*)c->spill.p, grid); }
     for (int it = 0; it < iters; it++) {
-        { Timed t(c, 1); fovpt_launch_trace(st, sc, ps, qa, cnt, it, (int*)c->spill.p, grid); }
-        { Timed t(c, 2); fovpt_launch_shade(st, fd, sc, ps, qa, qb, sq, cnt, it, grid); }
-        { Timed t(c, 3); fovpt_launch_shadow(st, sc, ps, sq, cnt, it, (int*)c->spill.p, grid); }
+        { Timed t(c, 2); fovpt_launch_shade(st, fd, sc, ps, qa, qb, sq, cap, cnt, it, grid); }
+        { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qb, sq, cap, cnt, it + 1 < iters ? it + 1 : -1, it, (int*)c->spill.p, grid); }
         uint32_t* tmp = qa; qa = qb; qb = tmp;
     }
     { Timed t(c, 4); fovpt_launch_resolve(st, fd, ps); }

@@ -14,6 +14,7 @@
 #define FOVPT_STACK_SPILL 48      // deeper entries go to a per-lane slice in HBM
 #define FOVPT_MAX_PASSES 3
 #define FOVPT_MAX_ITERS 63         // wavefront iterations per frame (max_depth + catcher pass-throughs)
+#define FOVPT_SHARDS 8            // queue shards: one append counter per blockIdx % 8 (~ per XCD)
 
 // One triangle in BVH leaf order, pre-subtracted edges (exactly v1-v0 and v2-v0 in fp32,
 // so Moeller-Trumbore gives the same bits as the contract in include/fovpt.h / oracle).
@@ -109,9 +110,12 @@ struct ShadowQueue {
     float4* val_occ;    // value added when occluded
 };
 
+// Queues are sharded: shard s of a queue with capacity `cap` lives at [s*cap, s*cap + count[s]).
+// One returning atomic on ONE word saturates at ~88/us on MI355X, so every producer block appends
+// to the counter of shard blockIdx % 8 with one atomic per block-iteration.
 struct Counters {       // device-resident, zeroed per frame except the stats block
-    uint32_t q[FOVPT_MAX_ITERS + 1];   // radiance queue sizes per iteration (q[0] = camera rays)
-    uint32_t sq[FOVPT_MAX_ITERS + 1];  // shadow queue sizes per iteration
+    uint32_t q[FOVPT_MAX_ITERS + 1][FOVPT_SHARDS];    // radiance queue sizes per iteration (q[0] = camera rays)
+    uint32_t sq[FOVPT_MAX_ITERS + 1][FOVPT_SHARDS];   // shadow queue sizes per iteration
     unsigned long long stat_radiance, stat_shadow, stat_paths;
 };
 
@@ -128,10 +132,13 @@ struct BvhBuildResult {
 hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* mesh_of_prim, uint32_t n,
                             BvhBuildResult* out, char* err, size_t errlen);
 
-void fovpt_launch_generate(hipStream_t st, const FrameDev& fd, PathState ps, uint32_t* queue0, Counters* cnt, uint32_t total_slots, int grid);
-void fovpt_launch_trace(hipStream_t st, SceneView sc, PathState ps, const uint32_t* queue, Counters* cnt, int depth, int* spill, int grid);
+// cap = shard capacity (in items) of the radiance queues and of the shadow queue.
+void fovpt_launch_generate(hipStream_t st, const FrameDev& fd, PathState ps, uint32_t* queue0, uint32_t cap, Counters* cnt, uint32_t total_slots, int grid);
+// One launch that traces the shadow queue of iteration it_shadow (if >= 0) and the radiance queue of
+// iteration it_closest (if >= 0).
+void fovpt_launch_traverse(hipStream_t st, SceneView sc, PathState ps, const uint32_t* queue, ShadowQueue sq, uint32_t cap,
+                           Counters* cnt, int it_closest, int it_shadow, int* spill, int grid);
 void fovpt_launch_shade(hipStream_t st, const FrameDev& fd, SceneView sc, PathState ps, const uint32_t* queue_in, uint32_t* queue_out,
-                        ShadowQueue sq, Counters* cnt, int depth, int grid);
-void fovpt_launch_shadow(hipStream_t st, SceneView sc, PathState ps, ShadowQueue sq, Counters* cnt, int depth, int* spill, int grid);
+                        ShadowQueue sq, uint32_t cap, Counters* cnt, int depth, int grid);
 void fovpt_launch_resolve(hipStream_t st, const FrameDev& fd, PathState ps);
 void fovpt_launch_math(hipStream_t st, int op, const float* a, const float* b, float* out, size_t n);

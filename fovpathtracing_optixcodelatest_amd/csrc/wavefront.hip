@@ -336,19 +336,52 @@ __device__ V3 bsdf_eval(const Mat& mat, const V3& albedo, float etaI, float etaO
 // ------------------------------------------------------------------------------------------
 // wavefront plumbing
 // ------------------------------------------------------------------------------------------
-// Ballot compaction: every lane with pred gets a distinct position; one atomic per wave.
-__device__ inline uint32_t wave_append(uint32_t* counter, bool pred)
+// Ballot compaction into a sharded queue.  Lanes with pred get distinct positions inside shard
+// blockIdx % 8: wave ballot + popcount prefix, the four wave totals meet in LDS, and ONE atomic per
+// block-iteration reserves the range.  Must be called by all 256 threads of the block (two barriers).
+__device__ inline uint32_t block_append(uint32_t* shard_counters, uint32_t cap, bool pred, uint32_t* s_scratch /* [6] */)
 {
     const unsigned long long mask = __ballot(pred);
-    if (mask == 0ull) return 0u;
     const uint32_t lane = __lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
     const uint32_t prefix = __popcll(mask & ((1ull << lane) - 1ull));
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = __shfl(base, leader);
-    return base + prefix;
+    if (lane == 0) s_scratch[wave] = (uint32_t)__popcll(mask);
+    __syncthreads();
+    const uint32_t c0 = s_scratch[0], c1 = s_scratch[1], c2 = s_scratch[2], c3 = s_scratch[3];
+    const uint32_t shard = blockIdx.x & (FOVPT_SHARDS - 1);
+    if (threadIdx.x == 0) {
+        const uint32_t total = c0 + c1 + c2 + c3;
+        s_scratch[4] = total ? atomicAdd(&shard_counters[shard], total) : 0u;
+    }
+    __syncthreads();
+    const uint32_t before = (wave > 0 ? c0 : 0u) + (wave > 1 ? c1 : 0u) + (wave > 2 ? c2 : 0u);
+    const uint32_t pos = shard * cap + s_scratch[4] + before + prefix;
+    __syncthreads();                 // s_scratch is reused by the next call
+    return pos;
 }
+
+// logical index -> physical index of a sharded queue (all in scalar registers, no indexing)
+struct ShardMap {
+    uint32_t p1, p2, p3, p4, p5, p6, p7, p8;     // exclusive prefix sums of the 8 shard counts (p0 = 0)
+    __device__ inline void load(const uint32_t* c)
+    {
+        p1 = c[0]; p2 = p1 + c[1]; p3 = p2 + c[2]; p4 = p3 + c[3];
+        p5 = p4 + c[4]; p6 = p5 + c[5]; p7 = p6 + c[6]; p8 = p7 + c[7];
+    }
+    __device__ inline uint32_t total() const { return p8; }
+    __device__ inline uint32_t phys(uint32_t i, uint32_t cap) const
+    {
+        uint32_t s = 0, base = 0;
+        if (i >= p1) { s = 1; base = p1; }
+        if (i >= p2) { s = 2; base = p2; }
+        if (i >= p3) { s = 3; base = p3; }
+        if (i >= p4) { s = 4; base = p4; }
+        if (i >= p5) { s = 5; base = p5; }
+        if (i >= p6) { s = 6; base = p6; }
+        if (i >= p7) { s = 7; base = p7; }
+        return s * cap + (i - base);
+    }
+};
 
 __device__ inline bool launch_owned(const FrameDev& fd, int p, uint32_t lx, uint32_t ly)
 {
@@ -368,9 +401,10 @@ __device__ inline bool ring_alive(const FrameDev& fd, const PassDev& P, uint32_t
 }
 
 // ---- generate ----------------------------------------------------------------------------
-__global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, PathState ps, uint32_t* __restrict__ queue0,
+__global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, PathState ps, uint32_t* __restrict__ queue0, uint32_t cap,
                                                           Counters* __restrict__ cnt, uint32_t total_slots)
 {
+    __shared__ uint32_t s_scratch[6];
     for (uint32_t base = blockIdx.x * FOVPT_BLOCK; base < total_slots; base += gridDim.x * FOVPT_BLOCK) {
         const uint32_t slot = base + threadIdx.x;
         bool live = slot < total_slots;
@@ -412,7 +446,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, Pat
                 ps.backplate[P.launch_base + ly * P.gw + lx] = probe_eval(fd.probe, u, v);
             }
         }
-        const uint32_t pos = wave_append(&cnt->q[0], live);
+        const uint32_t pos = block_append(cnt->q[0], cap, live, s_scratch);
         if (live) queue0[pos] = slot;
     }
 }
@@ -548,58 +582,62 @@ __device__ inline void traverse(const SceneView& sc, const RayT& r, Stack& st, f
     }
 }
 
-// closest hit over the radiance queue of this depth
-__global__ __launch_bounds__(FOVPT_BLOCK) void k_trace(SceneView sc, PathState ps, const uint32_t* __restrict__ queue,
-                                                       Counters* __restrict__ cnt, int depth, int* __restrict__ spill)
+// One traversal launch per bounce: the occlusion rays of iteration it_shadow and the closest-hit rays of
+// iteration it_closest form one index space [shadow | radiance], walked with a static grid-stride
+// loop (waves are homogeneous except the one at the seam).  The few, slow any-hit rays of one bounce
+// thus run beside the many closest-hit rays of the next instead of leaving the chip 60 % empty.
+// (Dynamic work fetching was measured and rejected: with <= 2 rays per resident lane per launch a
+// returning atomic per wave costs more than the imbalance it removes -- DESIGN.md section 4.)
+__global__ __launch_bounds__(FOVPT_BLOCK) void k_traverse(SceneView sc, PathState ps, const uint32_t* __restrict__ queue, ShadowQueue sq,
+                                                          uint32_t cap, Counters* __restrict__ cnt, int it_closest, int it_shadow,
+                                                          int* __restrict__ spill)
 {
     __shared__ int s_stack[FOVPT_STACK_LDS * FOVPT_BLOCK];
-    const uint32_t n = cnt->q[depth];
+    ShardMap ms, mq;
+    ms.load(cnt->sq[it_shadow >= 0 ? it_shadow : 0]);
+    mq.load(cnt->q[it_closest >= 0 ? it_closest : 0]);
+    const uint32_t n_sh = it_shadow >= 0 ? ms.total() : 0u;
+    const uint32_t n_cl = it_closest >= 0 ? mq.total() : 0u;
+    const uint32_t n_sh_pad = (n_sh + 63u) & ~63u;                 // keep waves homogeneous
+    const uint32_t n_total = n_sh_pad + n_cl;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-        atomicAdd(&cnt->stat_radiance, (unsigned long long)n);
-        if (depth == 0) atomicAdd(&cnt->stat_paths, (unsigned long long)n);
+        if (n_cl) atomicAdd(&cnt->stat_radiance, (unsigned long long)n_cl);
+        if (n_sh) atomicAdd(&cnt->stat_shadow, (unsigned long long)n_sh);
+        if (it_closest == 0) atomicAdd(&cnt->stat_paths, (unsigned long long)n_cl);
     }
     Stack st;
     st.lds = s_stack + threadIdx.x;
     st.stride = gridDim.x * FOVPT_BLOCK;
     st.spill = spill + blockIdx.x * FOVPT_BLOCK + threadIdx.x;
-    for (uint32_t i = blockIdx.x * FOVPT_BLOCK + threadIdx.x; i < n; i += gridDim.x * FOVPT_BLOCK) {
-        const uint32_t slot = queue[i];
-        RayT r;
-        ray_setup(r, ps.ray_o[slot], ps.ray_d[slot]);
-        float bt = INFINITY, bu = 0.f, bv = 0.f;
-        uint32_t bpos = 0xffffffffu, bprim = 0xffffffffu;
-        bool occ = false;
-        traverse<false>(sc, r, st, bt, bu, bv, bpos, bprim, occ);
-        ps.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(bpos));
-    }
-}
-
-// occlusion over the shadow queue of this depth; applies the deferred NEE contribution
-__global__ __launch_bounds__(FOVPT_BLOCK) void k_shadow(SceneView sc, PathState ps, ShadowQueue sq, Counters* __restrict__ cnt,
-                                                        int depth, int* __restrict__ spill)
-{
-    __shared__ int s_stack[FOVPT_STACK_LDS * FOVPT_BLOCK];
-    const uint32_t n = cnt->sq[depth];
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&cnt->stat_shadow, (unsigned long long)n);
-    Stack st;
-    st.lds = s_stack + threadIdx.x;
-    st.stride = gridDim.x * FOVPT_BLOCK;
-    st.spill = spill + blockIdx.x * FOVPT_BLOCK + threadIdx.x;
-    for (uint32_t i = blockIdx.x * FOVPT_BLOCK + threadIdx.x; i < n; i += gridDim.x * FOVPT_BLOCK) {
-        const float4 o = sq.o[i], d = sq.d[i];
-        RayT r;
-        ray_setup(r, o, d);
-        float bt = INFINITY, bu, bv;
-        uint32_t bpos, bprim = 0;
-        bool occ = false;
-        traverse<true>(sc, r, st, bt, bu, bv, bpos, bprim, occ);
-        const float4 val = occ ? sq.val_occ[i] : sq.val_vis[i];
-        const uint32_t slot = __float_as_uint(o.w);
-        const uint32_t target = __float_as_uint(d.w);
-        float4* acc = target == 0u ? ps.direct : (target == 1u ? ps.indirect : ps.alpha);
-        float4 a = acc[slot];
-        a.x += val.x; a.y += val.y; a.z += val.z;
-        acc[slot] = a;
+    for (uint32_t i = blockIdx.x * FOVPT_BLOCK + threadIdx.x; i < n_total; i += gridDim.x * FOVPT_BLOCK) {
+        if (i < n_sh_pad) {
+            if (i >= n_sh) continue;
+            const uint32_t ph = ms.phys(i, cap);
+            const float4 o = sq.o[ph], d = sq.d[ph];
+            RayT r;
+            ray_setup(r, o, d);
+            float bt = INFINITY, bu, bv;
+            uint32_t bpos, bprim = 0;
+            bool occ = false;
+            traverse<true>(sc, r, st, bt, bu, bv, bpos, bprim, occ);
+            // the deferred NEE add of SampleLights / SampleShadow (deviceProgram.cu:323-341,367-385)
+            const float4 val = occ ? sq.val_occ[ph] : sq.val_vis[ph];
+            const uint32_t slot = __float_as_uint(o.w);
+            const uint32_t target = __float_as_uint(d.w);
+            float4* acc = target == 0u ? ps.direct : (target == 1u ? ps.indirect : ps.alpha);
+            float4 a = acc[slot];
+            a.x += val.x; a.y += val.y; a.z += val.z;
+            acc[slot] = a;
+        } else {
+            const uint32_t slot = queue[mq.phys(i - n_sh_pad, cap)];
+            RayT r;
+            ray_setup(r, ps.ray_o[slot], ps.ray_d[slot]);
+            float bt = INFINITY, bu = 0.f, bv = 0.f;
+            uint32_t bpos = 0xffffffffu, bprim = 0xffffffffu;
+            bool occ = false;
+            traverse<false>(sc, r, st, bt, bu, bv, bpos, bprim, occ);
+            ps.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(bpos));
+        }
     }
 }
 
@@ -638,9 +676,12 @@ __device__ inline void acc_add(float4* acc, uint32_t slot, const V3& v)
 
 __global__ __launch_bounds__(FOVPT_BLOCK) void k_shade(const FrameDev fd, SceneView sc, PathState ps,
                                                        const uint32_t* __restrict__ queue_in, uint32_t* __restrict__ queue_out,
-                                                       ShadowQueue sq, Counters* __restrict__ cnt, int depth_iter)
+                                                       ShadowQueue sq, uint32_t cap, Counters* __restrict__ cnt, int depth_iter)
 {
-    const uint32_t n = cnt->q[depth_iter];
+    __shared__ uint32_t s_scratch[6];
+    ShardMap mq;
+    mq.load(cnt->q[depth_iter]);
+    const uint32_t n = mq.total();
     const uint32_t nround = (n + FOVPT_BLOCK - 1) / FOVPT_BLOCK * FOVPT_BLOCK;
     for (uint32_t i = blockIdx.x * FOVPT_BLOCK + threadIdx.x; i < nround; i += gridDim.x * FOVPT_BLOCK) {
         bool want_shadow = false, want_next = false;
@@ -648,7 +689,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_shade(const FrameDev fd, SceneV
         float4 sh_o, sh_d, sh_vis, sh_occ;
         sh_o = sh_d = sh_vis = sh_occ = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < n) {
-            slot = queue_in[i];
+            slot = queue_in[mq.phys(i, cap)];
             const float4 hit = ps.hit[slot];
             const uint32_t tpos = __float_as_uint(hit.w);
             uint4 rs = ps.rng[slot];
@@ -784,9 +825,9 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_shade(const FrameDev fd, SceneV
             ps.rng[slot] = rs;
         }
         // ---- wavefront-ballot compaction into the next queues
-        const uint32_t spos = wave_append(&cnt->sq[depth_iter], want_shadow);
+        const uint32_t spos = block_append(cnt->sq[depth_iter], cap, want_shadow, s_scratch);
         if (want_shadow) { sq.o[spos] = sh_o; sq.d[spos] = sh_d; sq.val_vis[spos] = sh_vis; sq.val_occ[spos] = sh_occ; }
-        const uint32_t qpos = wave_append(&cnt->q[depth_iter + 1], want_next);
+        const uint32_t qpos = block_append(cnt->q[depth_iter + 1], cap, want_next, s_scratch);
         if (want_next) queue_out[qpos] = slot;
     }
 }
@@ -906,22 +947,19 @@ __global__ void k_math(int op, const float* a, const float* b, float* out, size_
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
-void fovpt_launch_generate(hipStream_t st, const FrameDev& fd, PathState ps, uint32_t* queue0, Counters* cnt, uint32_t total_slots, int grid)
+void fovpt_launch_generate(hipStream_t st, const FrameDev& fd, PathState ps, uint32_t* queue0, uint32_t cap, Counters* cnt, uint32_t total_slots, int grid)
 {
-    hipLaunchKernelGGL(k_generate, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, ps, queue0, cnt, total_slots);
+    hipLaunchKernelGGL(k_generate, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, ps, queue0, cap, cnt, total_slots);
 }
-void fovpt_launch_trace(hipStream_t st, SceneView sc, PathState ps, const uint32_t* queue, Counters* cnt, int depth, int* spill, int grid)
+void fovpt_launch_traverse(hipStream_t st, SceneView sc, PathState ps, const uint32_t* queue, ShadowQueue sq, uint32_t cap,
+                           Counters* cnt, int it_closest, int it_shadow, int* spill, int grid)
 {
-    hipLaunchKernelGGL(k_trace, dim3(grid), dim3(FOVPT_BLOCK), 0, st, sc, ps, queue, cnt, depth, spill);
+    hipLaunchKernelGGL(k_traverse, dim3(grid), dim3(FOVPT_BLOCK), 0, st, sc, ps, queue, sq, cap, cnt, it_closest, it_shadow, spill);
 }
 void fovpt_launch_shade(hipStream_t st, const FrameDev& fd, SceneView sc, PathState ps, const uint32_t* queue_in, uint32_t* queue_out,
-                        ShadowQueue sq, Counters* cnt, int depth, int grid)
+                        ShadowQueue sq, uint32_t cap, Counters* cnt, int depth, int grid)
 {
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, sc, ps, queue_in, queue_out, sq, cnt, depth);
-}
-void fovpt_launch_shadow(hipStream_t st, SceneView sc, PathState ps, ShadowQueue sq, Counters* cnt, int depth, int* spill, int grid)
-{
-    hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(FOVPT_BLOCK), 0, st, sc, ps, sq, cnt, depth, spill);
+    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, sc, ps, queue_in, queue_out, sq, cap, cnt, depth);
 }
 void fovpt_launch_resolve(hipStream_t st, const FrameDev& fd, PathState ps)
 {
