@@ -250,11 +250,159 @@ __global__ void k_iota(uint32_t* v, uint32_t n)
     if (i < n) v[i] = i;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// PLOC (parallel locally-ordered clustering, Meister & Bittner 2018) on the Morton-sorted
+// primitives: SAH-guided bottom-up agglomeration -- the "SAH refit" of the LBVH order.  Each
+// round every cluster looks FOVPT_PLOC_RADIUS neighbours left and right along the Morton curve for
+// the partner that minimises the surface area of the merged box; mutual choices merge.
+// ------------------------------------------------------------------------------------------
+#define FOVPT_PLOC_RADIUS 16
+
+__device__ inline float union_area(const Box& a, const Box& b)
+{
+    const float dx = fmaxf(a.hi[0], b.hi[0]) - fminf(a.lo[0], b.lo[0]);
+    const float dy = fmaxf(a.hi[1], b.hi[1]) - fminf(a.lo[1], b.lo[1]);
+    const float dz = fmaxf(a.hi[2], b.hi[2]) - fminf(a.lo[2], b.lo[2]);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ void k_ploc_init(int n, const Box* __restrict__ boxes, const uint32_t* __restrict__ vals, int* __restrict__ c_node, Box* __restrict__ c_box)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    c_node[i] = ~i;                       // leaf at sorted position i
+    c_box[i] = boxes[vals[i]];
+}
+
+__global__ void k_ploc_nn(int n, int force, const Box* __restrict__ c_box, int* __restrict__ nn)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (force) { int j = i ^ 1; nn[i] = j < n ? j : i; return; }
+    const Box me = c_box[i];
+    float best = INFINITY;
+    int bj = i;
+    const int lo = max(0, i - FOVPT_PLOC_RADIUS), hi = min(n - 1, i + FOVPT_PLOC_RADIUS);
+    for (int j = lo; j <= hi; j++) {
+        if (j == i) continue;
+        const float a = union_area(me, c_box[j]);
+        if (a < best) { best = a; bj = j; }
+    }
+    nn[i] = bj;
+}
+
+// children coded: >= 0 internal node id, < 0 ~sorted leaf position
+__global__ void k_ploc_merge(int n, const int* __restrict__ c_node, const Box* __restrict__ c_box, const int* __restrict__ nn,
+                             uint32_t* __restrict__ node_counter, int* __restrict__ left, int* __restrict__ right,
+                             int* __restrict__ parent_int, int* __restrict__ parent_leaf, unsigned char* __restrict__ side_int,
+                             unsigned char* __restrict__ side_leaf, Box* __restrict__ ibox, uint32_t* __restrict__ size_int,
+                             uint32_t* __restrict__ valid, int* __restrict__ t_node, Box* __restrict__ t_box)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int j = nn[i];
+    const bool mutual = j != i && nn[j] == i;
+    if (!mutual) { valid[i] = 1u; t_node[i] = c_node[i]; t_box[i] = c_box[i]; return; }
+    if (i > j) { valid[i] = 0u; return; }
+    const int node = (int)atomicAdd(node_counter, 1u);
+    const int a = c_node[i], b = c_node[j];
+    const Box ba = c_box[i], bb = c_box[j];
+    Box u;
+    for (int k = 0; k < 3; k++) { u.lo[k] = fminf(ba.lo[k], bb.lo[k]); u.hi[k] = fmaxf(ba.hi[k], bb.hi[k]); }
+    left[node] = a; right[node] = b;
+    ibox[node] = u;
+    size_int[node] = (a < 0 ? 1u : size_int[a]) + (b < 0 ? 1u : size_int[b]);
+    parent_int[node] = -1;
+    if (a < 0) { parent_leaf[~a] = node; side_leaf[~a] = 0; } else { parent_int[a] = node; side_int[a] = 0; }
+    if (b < 0) { parent_leaf[~b] = node; side_leaf[~b] = 1; } else { parent_int[b] = node; side_int[b] = 1; }
+    valid[i] = 1u; t_node[i] = node; t_box[i] = u;
+}
+
+__global__ void k_ploc_compact(int n, const uint32_t* __restrict__ valid, const uint32_t* __restrict__ pos,
+                               const int* __restrict__ t_node, const Box* __restrict__ t_box, int* __restrict__ c_node, Box* __restrict__ c_box)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !valid[i]) return;
+    c_node[pos[i]] = t_node[i];
+    c_box[pos[i]] = t_box[i];
+}
+
+// depth-first position of every leaf and first position of every internal node: climb to the root,
+// adding the size of the left sibling whenever we come up from a right child
+__global__ void k_dfs_offsets(int n, const int* __restrict__ left, const int* __restrict__ parent_int, const int* __restrict__ parent_leaf,
+                              const unsigned char* __restrict__ side_int, const unsigned char* __restrict__ side_leaf,
+                              const uint32_t* __restrict__ size_int, uint32_t* __restrict__ leaf_pos, uint32_t* __restrict__ node_first,
+                              uint32_t* __restrict__ node_depth)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * n - 1) return;
+    const bool is_leaf = i < n;
+    int cur = is_leaf ? parent_leaf[i] : parent_int[i - n];
+    unsigned char side = is_leaf ? side_leaf[i] : side_int[i - n];
+    uint32_t off = 0, depth = 0;
+    while (cur >= 0) {
+        if (side) { const int l = left[cur]; off += l < 0 ? 1u : size_int[l]; }
+        side = side_int[cur];
+        cur = parent_int[cur];
+        depth++;
+    }
+    if (is_leaf) leaf_pos[i] = off;
+    else { node_first[i - n] = off; node_depth[i - n] = depth; }
+}
+
+// traversal nodes from a generic binary tree; node k is stored at index root - k (root = n-2 first)
+__global__ void k_emit_nodes_generic(int n, const int* __restrict__ left, const int* __restrict__ right, const uint32_t* __restrict__ size_int,
+                                     const uint32_t* __restrict__ node_first, const uint32_t* __restrict__ leaf_pos,
+                                     const uint32_t* __restrict__ node_depth, const Box* __restrict__ boxes, const uint32_t* __restrict__ vals,
+                                     const Box* __restrict__ ibox, BvhNode* __restrict__ nodes, uint32_t* __restrict__ stats)
+{
+    int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n - 1) return;
+    const int root = n - 2;
+    if (size_int[k] <= FOVPT_LEAF_MAX && k != root) return;
+    int code[2];
+    Box cb[2];
+    const int ch[2] = {left[k], right[k]};
+    for (int c = 0; c < 2; c++) {
+        const int x = ch[c];
+        if (x < 0) { code[c] = leaf_code((int)leaf_pos[~x], 1); cb[c] = boxes[vals[~x]]; }
+        else {
+            code[c] = size_int[x] <= FOVPT_LEAF_MAX ? leaf_code((int)node_first[x], (int)size_int[x]) : root - x;
+            cb[c] = ibox[x];
+        }
+    }
+    BvhNode nd;
+    nd.lo0x = cb[0].lo[0]; nd.lo0y = cb[0].lo[1]; nd.lo0z = cb[0].lo[2];
+    nd.hi0x = cb[0].hi[0]; nd.hi0y = cb[0].hi[1]; nd.hi0z = cb[0].hi[2];
+    nd.lo1x = cb[1].lo[0]; nd.lo1y = cb[1].lo[1]; nd.lo1z = cb[1].lo[2];
+    nd.hi1x = cb[1].hi[0]; nd.hi1y = cb[1].hi[1]; nd.hi1z = cb[1].hi[2];
+    nd.c0 = code[0]; nd.c1 = code[1]; nd.pad0 = nd.pad1 = 0;
+    nodes[root - k] = nd;
+    atomicMax(&stats[0], node_depth[k] + 1u);
+    atomicAdd(&stats[1], 1u);
+}
+
+__global__ void k_emit_tris_generic(const float* __restrict__ flat, const uint32_t* __restrict__ mesh_of_prim, const uint32_t* __restrict__ vals,
+                                    const uint32_t* __restrict__ leaf_pos, uint32_t n, TriRec* __restrict__ tris)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t prim = vals[i];
+    const float* p = flat + (size_t)prim * 9;
+    TriRec t;
+    t.v0x = p[0]; t.v0y = p[1]; t.v0z = p[2];
+    t.e1x = p[3] - p[0]; t.e1y = p[4] - p[1]; t.e1z = p[5] - p[2];
+    t.e2x = p[6] - p[0]; t.e2y = p[7] - p[1]; t.e2z = p[8] - p[2];
+    t.prim = prim; t.mesh = mesh_of_prim[prim]; t.pad = 0;
+    tris[leaf_pos[i]] = t;
+}
+
 #define HC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(err, errlen, "%s failed: %s", #x, hipGetErrorString(e_)); goto fail; } } while (0)
 
 }  // namespace
 
-hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* mesh_of_prim, uint32_t n,
+hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* mesh_of_prim, uint32_t n, int use_ploc,
                             BvhBuildResult* out, char* err, size_t errlen)
 {
     Box *boxes = nullptr, *ibox = nullptr;
@@ -263,6 +411,13 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
     int *left = nullptr, *right = nullptr, *parent_int = nullptr, *parent_leaf = nullptr, *rfirst = nullptr, *rlast = nullptr;
     void* temp = nullptr;
     size_t temp_bytes = 0;
+    // PLOC state
+    int *c_node = nullptr, *t_node = nullptr, *nn = nullptr;
+    Box *c_box = nullptr, *t_box = nullptr;
+    uint32_t *valid = nullptr, *pos = nullptr, *node_counter = nullptr, *size_int = nullptr, *leaf_pos = nullptr, *node_first = nullptr, *node_depth = nullptr;
+    unsigned char *side_int = nullptr, *side_leaf = nullptr;
+    void* scan_temp = nullptr;
+    size_t scan_bytes = 0;
     BvhNode* nodes = nullptr;
     TriRec* tris = nullptr;
     const uint32_t ni = n > 1 ? n - 1 : 1;
@@ -300,11 +455,51 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
         HC(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys, keys_s, vals, vals_s, (size_t)n, 0, 63, st));
         HC(hipMalloc(&temp, temp_bytes));
         HC(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_s, vals, vals_s, (size_t)n, 0, 63, st));
-        hipLaunchKernelGGL(k_hierarchy, dim3(gi), dim3(B), 0, st, keys_s, (int)n, left, right, parent_int, parent_leaf, rfirst, rlast);
-        hipLaunchKernelGGL(k_refit, dim3(gn), dim3(B), 0, st, boxes, vals_s, (int)n, left, right, parent_int, parent_leaf, ibox, arrive);
-        hipLaunchKernelGGL(k_emit_nodes, dim3(gi), dim3(B), 0, st, (int)n, left, right, rfirst, rlast, boxes, vals_s, ibox, parent_int, nodes, stats);
+        if (!use_ploc) {
+            hipLaunchKernelGGL(k_hierarchy, dim3(gi), dim3(B), 0, st, keys_s, (int)n, left, right, parent_int, parent_leaf, rfirst, rlast);
+            hipLaunchKernelGGL(k_refit, dim3(gn), dim3(B), 0, st, boxes, vals_s, (int)n, left, right, parent_int, parent_leaf, ibox, arrive);
+            hipLaunchKernelGGL(k_emit_nodes, dim3(gi), dim3(B), 0, st, (int)n, left, right, rfirst, rlast, boxes, vals_s, ibox, parent_int, nodes, stats);
+        } else {
+            HC(hipMalloc(&c_node, 4ull * n)); HC(hipMalloc(&t_node, 4ull * n)); HC(hipMalloc(&nn, 4ull * n));
+            HC(hipMalloc(&c_box, sizeof(Box) * n)); HC(hipMalloc(&t_box, sizeof(Box) * n));
+            HC(hipMalloc(&valid, 4ull * n)); HC(hipMalloc(&pos, 4ull * n));
+            HC(hipMalloc(&node_counter, 4)); HC(hipMalloc(&size_int, 4ull * ni));
+            HC(hipMalloc(&leaf_pos, 4ull * n)); HC(hipMalloc(&node_first, 4ull * ni)); HC(hipMalloc(&node_depth, 4ull * ni));
+            HC(hipMalloc(&side_int, ni)); HC(hipMalloc(&side_leaf, n));
+            HC(hipMemsetAsync(node_counter, 0, 4, st));
+            HC(hipMemsetAsync(side_int, 0, ni, st));
+            HC(rocprim::exclusive_scan(nullptr, scan_bytes, valid, pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), st));
+            HC(hipMalloc(&scan_temp, scan_bytes));
+            hipLaunchKernelGGL(k_ploc_init, dim3(gn), dim3(B), 0, st, (int)n, boxes, vals_s, c_node, c_box);
+            uint32_t m = n;
+            int force = 0, rounds = 0;
+            while (m > 1) {
+                const uint32_t gm = (m + B - 1) / B;
+                hipLaunchKernelGGL(k_ploc_nn, dim3(gm), dim3(B), 0, st, (int)m, force, c_box, nn);
+                hipLaunchKernelGGL(k_ploc_merge, dim3(gm), dim3(B), 0, st, (int)m, c_node, c_box, nn, node_counter, left, right, parent_int,
+                                   parent_leaf, side_int, side_leaf, ibox, size_int, valid, t_node, t_box);
+                HC(rocprim::exclusive_scan(scan_temp, scan_bytes, valid, pos, 0u, (size_t)m, rocprim::plus<uint32_t>(), st));
+                hipLaunchKernelGGL(k_ploc_compact, dim3(gm), dim3(B), 0, st, (int)m, valid, pos, t_node, t_box, c_node, c_box);
+                uint32_t last_pos = 0, last_valid = 0;
+                HC(hipMemcpyAsync(&last_pos, pos + (m - 1), 4, hipMemcpyDeviceToHost, st));
+                HC(hipMemcpyAsync(&last_valid, valid + (m - 1), 4, hipMemcpyDeviceToHost, st));
+                HC(hipStreamSynchronize(st));
+                const uint32_t m2 = last_pos + last_valid;
+                force = (m2 == m) ? 1 : 0;                     // no mutual pair this round (ties): pair neighbours next round
+                m = m2;
+                if (++rounds > 4096) { snprintf(err, errlen, "PLOC did not converge"); goto fail; }
+            }
+            const uint32_t gall = (2 * n - 1 + B - 1) / B;
+            hipLaunchKernelGGL(k_dfs_offsets, dim3(gall), dim3(B), 0, st, (int)n, left, parent_int, parent_leaf, side_int, side_leaf, size_int,
+                               leaf_pos, node_first, node_depth);
+            hipLaunchKernelGGL(k_emit_nodes_generic, dim3(gi), dim3(B), 0, st, (int)n, left, right, size_int, node_first, leaf_pos, node_depth,
+                               boxes, vals_s, ibox, nodes, stats);
+        }
     }
-    hipLaunchKernelGGL(k_emit_tris, dim3(gn), dim3(B), 0, st, flat, mesh_of_prim, vals_s, n, tris);
+    if (use_ploc && n > FOVPT_LEAF_MAX)
+        hipLaunchKernelGGL(k_emit_tris_generic, dim3(gn), dim3(B), 0, st, flat, mesh_of_prim, vals_s, leaf_pos, n, tris);
+    else
+        hipLaunchKernelGGL(k_emit_tris, dim3(gn), dim3(B), 0, st, flat, mesh_of_prim, vals_s, n, tris);
     HC(hipGetLastError());
     HC(hipMemcpyAsync(h_stats, stats, 8, hipMemcpyDeviceToHost, st));
     HC(hipStreamSynchronize(st));
@@ -320,5 +515,8 @@ fail:
     (void)hipFree(boxes); (void)hipFree(ibox); (void)hipFree(bounds); (void)hipFree(stats); (void)hipFree(keys); (void)hipFree(keys_s);
     (void)hipFree(vals); (void)hipFree(vals_s); (void)hipFree(arrive); (void)hipFree(left); (void)hipFree(right); (void)hipFree(parent_int);
     (void)hipFree(parent_leaf); (void)hipFree(rfirst); (void)hipFree(rlast); (void)hipFree(temp); (void)hipFree(nodes); (void)hipFree(tris);
+    (void)hipFree(c_node); (void)hipFree(t_node); (void)hipFree(nn); (void)hipFree(c_box); (void)hipFree(t_box); (void)hipFree(valid); (void)hipFree(pos);
+    (void)hipFree(node_counter); (void)hipFree(size_int); (void)hipFree(leaf_pos); (void)hipFree(node_first); (void)hipFree(node_depth);
+    (void)hipFree(side_int); (void)hipFree(side_leaf); (void)hipFree(scan_temp);
     return rc;
 }

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -377,7 +378,9 @@ int fovpt_set_scene(fovpt_ctx* c, const fovpt_mesh_desc* meshes, int num_meshes,
     BvhBuildResult br;
     memset(&br, 0, sizeof(br));
     char errbuf[256];
-    hipError_t be = fovpt_build_lbvh(c->stream, d_flat, d_mesh_of, (uint32_t)ntri, &br, errbuf, sizeof(errbuf));
+    const char* bvh_env = getenv("FOVPT_BVH");          // "lbvh" = plain Karras tree (A/B testing); default PLOC
+    const int use_ploc = !(bvh_env && strcmp(bvh_env, "lbvh") == 0);
+    hipError_t be = fovpt_build_lbvh(c->stream, d_flat, d_mesh_of, (uint32_t)ntri, use_ploc, &br, errbuf, sizeof(errbuf));
     (void)hipEventRecord(e1, c->stream);
     (void)hipEventSynchronize(e1);
     float ms = 0.f;

@@ -129,7 +129,7 @@ struct BvhBuildResult {
 };
 
 // flat: 9 floats per triangle (v0,v1,v2), mesh_of_prim: mesh id per triangle.  All device pointers.
-hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* mesh_of_prim, uint32_t n,
+hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* mesh_of_prim, uint32_t n, int use_ploc,
                             BvhBuildResult* out, char* err, size_t errlen);
 
 // cap = shard capacity (in items) of the radiance queues and of the shadow queue.
