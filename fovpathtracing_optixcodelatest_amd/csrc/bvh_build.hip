@@ -7,8 +7,10 @@
 //   3. rocPRIM radix sort of (code, primitive)
 //   4. Karras 2012 binary radix tree (one thread per internal node)
 //   5. bottom-up AABB refit with per-node arrival counters
-//   6. collapse subtrees of <= FOVPT_LEAF_MAX triangles into leaves and emit 64-byte nodes that
-//      carry both child boxes; emit 48-byte triangle records in leaf order
+//      (4'/5': default instead of 4/5 -- PLOC, SAH-guided agglomeration along the Morton order)
+//   6. collapse subtrees of <= FOVPT_LEAF_MAX triangles into leaves, collapse the binary tree
+//      top-down into 4-wide 128-byte nodes (largest-area child expanded first), breadth-first
+//      node order; emit 48-byte triangle records in depth-first leaf order
 // Results never depend on the tree (see the intersection contract in include/fovpt.h), only
 // speed does.
 #include <cstdio>
@@ -173,77 +175,6 @@ __global__ void k_refit(const Box* __restrict__ boxes, const uint32_t* __restric
 
 __device__ inline int leaf_code(int first, int count) { return ~((first << 3) | (count - 1)); }
 
-// 6a. emit traversal nodes (sparse: node i keeps its Karras index)
-__global__ void k_emit_nodes(int n, const int* __restrict__ left, const int* __restrict__ right,
-                             const int* __restrict__ rfirst, const int* __restrict__ rlast,
-                             const Box* __restrict__ boxes, const uint32_t* __restrict__ vals, const Box* __restrict__ ibox,
-                             const int* __restrict__ parent_int, BvhNode* __restrict__ nodes, uint32_t* __restrict__ stats)
-{
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n - 1) return;
-    int size = rlast[i] - rfirst[i] + 1;
-    if (size <= FOVPT_LEAF_MAX && i != 0) return;        // collapsed into an ancestor's leaf reference
-    int code[2];
-    Box cb[2];
-    int ch[2] = {left[i], right[i]};
-    for (int k = 0; k < 2; k++) {
-        int c = ch[k];
-        if (c < 0) {
-            int pos = ~c;
-            code[k] = leaf_code(pos, 1);
-            cb[k] = boxes[vals[pos]];
-        } else {
-            int sz = rlast[c] - rfirst[c] + 1;
-            code[k] = sz <= FOVPT_LEAF_MAX ? leaf_code(rfirst[c], sz) : c;
-            cb[k] = ibox[c];
-        }
-    }
-    BvhNode nd;
-    nd.lo0x = cb[0].lo[0]; nd.lo0y = cb[0].lo[1]; nd.lo0z = cb[0].lo[2];
-    nd.hi0x = cb[0].hi[0]; nd.hi0y = cb[0].hi[1]; nd.hi0z = cb[0].hi[2];
-    nd.lo1x = cb[1].lo[0]; nd.lo1y = cb[1].lo[1]; nd.lo1z = cb[1].lo[2];
-    nd.hi1x = cb[1].hi[0]; nd.hi1y = cb[1].hi[1]; nd.hi1z = cb[1].hi[2];
-    nd.c0 = code[0]; nd.c1 = code[1]; nd.pad0 = nd.pad1 = 0;
-    nodes[i] = nd;
-    // depth of this node = number of kept ancestors + 1
-    int depth = 1;
-    for (int p = parent_int[i]; p >= 0; p = parent_int[p]) depth++;
-    atomicMax(&stats[0], (uint32_t)depth);
-    atomicAdd(&stats[1], 1u);
-}
-
-// tiny scenes (n <= FOVPT_LEAF_MAX): a root whose first child is the only leaf
-__global__ void k_emit_tiny(int n, const Box* __restrict__ boxes, BvhNode* __restrict__ nodes, uint32_t* __restrict__ stats)
-{
-    Box u = boxes[0];
-    for (int i = 1; i < n; i++)
-        for (int k = 0; k < 3; k++) { u.lo[k] = fminf(u.lo[k], boxes[i].lo[k]); u.hi[k] = fmaxf(u.hi[k], boxes[i].hi[k]); }
-    BvhNode nd;
-    nd.lo0x = u.lo[0]; nd.lo0y = u.lo[1]; nd.lo0z = u.lo[2];
-    nd.hi0x = u.hi[0]; nd.hi0y = u.hi[1]; nd.hi0z = u.hi[2];
-    nd.lo1x = nd.lo1y = nd.lo1z = INFINITY;      // empty child: a point at +inf never passes the slab test
-    nd.hi1x = nd.hi1y = nd.hi1z = INFINITY;
-    nd.c0 = leaf_code(0, n); nd.c1 = leaf_code(0, 1); nd.pad0 = nd.pad1 = 0;
-    nodes[0] = nd;
-    stats[0] = 1; stats[1] = 1;
-}
-
-// 6b. triangle records in leaf (sorted) order
-__global__ void k_emit_tris(const float* __restrict__ flat, const uint32_t* __restrict__ mesh_of_prim,
-                            const uint32_t* __restrict__ vals, uint32_t n, TriRec* __restrict__ tris)
-{
-    uint32_t pos = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos >= n) return;
-    uint32_t prim = vals[pos];
-    const float* p = flat + (size_t)prim * 9;
-    TriRec t;
-    t.v0x = p[0]; t.v0y = p[1]; t.v0z = p[2];
-    t.e1x = p[3] - p[0]; t.e1y = p[4] - p[1]; t.e1z = p[5] - p[2];
-    t.e2x = p[6] - p[0]; t.e2y = p[7] - p[1]; t.e2z = p[8] - p[2];
-    t.prim = prim; t.mesh = mesh_of_prim[prim]; t.pad = 0;
-    tris[pos] = t;
-}
-
 __global__ void k_iota(uint32_t* v, uint32_t n)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -351,36 +282,104 @@ __global__ void k_dfs_offsets(int n, const int* __restrict__ left, const int* __
     else { node_first[i - n] = off; node_depth[i - n] = depth; }
 }
 
-// traversal nodes from a generic binary tree; node k is stored at index root - k (root = n-2 first)
-__global__ void k_emit_nodes_generic(int n, const int* __restrict__ left, const int* __restrict__ right, const uint32_t* __restrict__ size_int,
-                                     const uint32_t* __restrict__ node_first, const uint32_t* __restrict__ leaf_pos,
-                                     const uint32_t* __restrict__ node_depth, const Box* __restrict__ boxes, const uint32_t* __restrict__ vals,
-                                     const Box* __restrict__ ibox, BvhNode* __restrict__ nodes, uint32_t* __restrict__ stats)
+// LBVH (Karras) trees in the generic form: subtree sizes and first positions come from the ranges
+__global__ void k_lbvh_generic(int n, const int* __restrict__ rfirst, const int* __restrict__ rlast,
+                               uint32_t* __restrict__ size_int, uint32_t* __restrict__ node_first, uint32_t* __restrict__ leaf_pos)
 {
-    int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n - 1) return;
-    const int root = n - 2;
-    if (size_int[k] <= FOVPT_LEAF_MAX && k != root) return;
-    int code[2];
-    Box cb[2];
-    const int ch[2] = {left[k], right[k]};
-    for (int c = 0; c < 2; c++) {
-        const int x = ch[c];
-        if (x < 0) { code[c] = leaf_code((int)leaf_pos[~x], 1); cb[c] = boxes[vals[~x]]; }
-        else {
-            code[c] = size_int[x] <= FOVPT_LEAF_MAX ? leaf_code((int)node_first[x], (int)size_int[x]) : root - x;
-            cb[c] = ibox[x];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) leaf_pos[i] = (uint32_t)i;
+    if (i < n - 1) { size_int[i] = (uint32_t)(rlast[i] - rfirst[i] + 1); node_first[i] = (uint32_t)rfirst[i]; }
+}
+
+struct Work4 { int node; uint32_t out; uint32_t depth; };
+
+__device__ inline float box_area(const Box& b)
+{
+    const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// One level of the top-down 2 -> 4 collapse: every work item is a binary node that becomes a wide node.
+// Its two children are expanded (largest surface area first) until four slots are used or nothing is
+// left to expand; children that stay internal are queued for the next level.
+__global__ void k_collapse4(int nwork, const Work4* __restrict__ work_in, Work4* __restrict__ work_out, uint32_t* __restrict__ counters,
+                            const int* __restrict__ left, const int* __restrict__ right, const uint32_t* __restrict__ size_int,
+                            const uint32_t* __restrict__ node_first, const uint32_t* __restrict__ leaf_pos,
+                            const Box* __restrict__ boxes, const uint32_t* __restrict__ vals, const Box* __restrict__ ibox,
+                            BvhNode4* __restrict__ nodes, uint32_t* __restrict__ stats)
+{
+    int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwork) return;
+    const Work4 me = work_in[w];
+    int ch[4];
+    int nch = 2;
+    ch[0] = left[me.node]; ch[1] = right[me.node];
+    for (;;) {
+        if (nch == 4) break;
+        int pick = -1;
+        float best = -1.0f;
+        for (int k = 0; k < nch; k++) {
+            const int x = ch[k];
+            if (x < 0 || size_int[x] <= FOVPT_LEAF_MAX) continue;          // leaf or collapsed leaf: not expandable
+            const float a = box_area(ibox[x]);
+            if (a > best) { best = a; pick = k; }
         }
+        if (pick < 0) break;
+        const int x = ch[pick];
+        ch[pick] = left[x];
+        ch[nch++] = right[x];
     }
-    BvhNode nd;
-    nd.lo0x = cb[0].lo[0]; nd.lo0y = cb[0].lo[1]; nd.lo0z = cb[0].lo[2];
-    nd.hi0x = cb[0].hi[0]; nd.hi0y = cb[0].hi[1]; nd.hi0z = cb[0].hi[2];
-    nd.lo1x = cb[1].lo[0]; nd.lo1y = cb[1].lo[1]; nd.lo1z = cb[1].lo[2];
-    nd.hi1x = cb[1].hi[0]; nd.hi1y = cb[1].hi[1]; nd.hi1z = cb[1].hi[2];
-    nd.c0 = code[0]; nd.c1 = code[1]; nd.pad0 = nd.pad1 = 0;
-    nodes[root - k] = nd;
-    atomicMax(&stats[0], node_depth[k] + 1u);
+    BvhNode4 nd;
+    for (int k = 0; k < 4; k++) {
+        nd.lox[k] = nd.loy[k] = nd.loz[k] = INFINITY;          // empty slot: a point at +inf never passes the slab test
+        nd.hix[k] = nd.hiy[k] = nd.hiz[k] = INFINITY;
+        nd.child[k] = leaf_code(0, 1);
+        nd.pad[k] = 0;
+    }
+    for (int k = 0; k < nch; k++) {
+        const int x = ch[k];
+        Box b;
+        int code;
+        if (x < 0) { b = boxes[vals[~x]]; code = leaf_code((int)leaf_pos[~x], 1); }
+        else {
+            b = ibox[x];
+            if (size_int[x] <= FOVPT_LEAF_MAX) code = leaf_code((int)node_first[x], (int)size_int[x]);
+            else {
+                const uint32_t slot = atomicAdd(&counters[0], 1u);          // next free wide node
+                const uint32_t q = atomicAdd(&counters[1], 1u);             // next level's queue
+                Work4 nw; nw.node = x; nw.out = slot; nw.depth = me.depth + 1;
+                work_out[q] = nw;
+                code = (int)slot;
+            }
+        }
+        nd.lox[k] = b.lo[0]; nd.loy[k] = b.lo[1]; nd.loz[k] = b.lo[2];
+        nd.hix[k] = b.hi[0]; nd.hiy[k] = b.hi[1]; nd.hiz[k] = b.hi[2];
+        nd.child[k] = code;
+    }
+    nodes[me.out] = nd;
+    atomicMax(&stats[0], me.depth + 1u);
     atomicAdd(&stats[1], 1u);
+}
+
+// tiny scenes (n <= FOVPT_LEAF_MAX): a root whose first child is the only leaf
+__global__ void k_emit_tiny(int n, const Box* __restrict__ boxes, BvhNode4* __restrict__ nodes, uint32_t* __restrict__ stats, uint32_t* __restrict__ leaf_pos)
+{
+    Box u = boxes[0];
+    for (int i = 1; i < n; i++)
+        for (int k = 0; k < 3; k++) { u.lo[k] = fminf(u.lo[k], boxes[i].lo[k]); u.hi[k] = fmaxf(u.hi[k], boxes[i].hi[k]); }
+    BvhNode4 nd;
+    for (int k = 0; k < 4; k++) {
+        nd.lox[k] = nd.loy[k] = nd.loz[k] = INFINITY;
+        nd.hix[k] = nd.hiy[k] = nd.hiz[k] = INFINITY;
+        nd.child[k] = leaf_code(0, 1);
+        nd.pad[k] = 0;
+    }
+    nd.lox[0] = u.lo[0]; nd.loy[0] = u.lo[1]; nd.loz[0] = u.lo[2];
+    nd.hix[0] = u.hi[0]; nd.hiy[0] = u.hi[1]; nd.hiz[0] = u.hi[2];
+    nd.child[0] = leaf_code(0, n);
+    nodes[0] = nd;
+    stats[0] = 1; stats[1] = 1;
+    for (int i = 0; i < n; i++) leaf_pos[i] = (uint32_t)i;
 }
 
 __global__ void k_emit_tris_generic(const float* __restrict__ flat, const uint32_t* __restrict__ mesh_of_prim, const uint32_t* __restrict__ vals,
@@ -418,13 +417,17 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
     unsigned char *side_int = nullptr, *side_leaf = nullptr;
     void* scan_temp = nullptr;
     size_t scan_bytes = 0;
-    BvhNode* nodes = nullptr;
+    // collapse state
+    Work4 *work_a = nullptr, *work_b = nullptr;
+    uint32_t* counters = nullptr;
+    BvhNode4* nodes = nullptr;
     TriRec* tris = nullptr;
     const uint32_t ni = n > 1 ? n - 1 : 1;
     const int B = 256;
     const uint32_t gn = (n + B - 1) / B, gi = (ni + B - 1) / B;
     uint32_t h_bounds[6];
     uint32_t h_stats[2] = {0, 0};
+    uint32_t h_counters[2] = {1, 0};
     hipError_t rc = hipSuccess;
     err[0] = 0;
     for (int a = 0; a < 3; a++) { h_bounds[a] = 0xffffffffu; h_bounds[3 + a] = 0u; }
@@ -433,38 +436,40 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
     HC(hipMalloc(&ibox, sizeof(Box) * ni));
     HC(hipMalloc(&bounds, 6 * 4));
     HC(hipMalloc(&stats, 2 * 4));
+    HC(hipMalloc(&counters, 2 * 4));
     HC(hipMalloc(&keys, 8ull * n)); HC(hipMalloc(&keys_s, 8ull * n));
     HC(hipMalloc(&vals, 4ull * n)); HC(hipMalloc(&vals_s, 4ull * n));
-    HC(hipMalloc(&arrive, 4ull * ni));
     HC(hipMalloc(&left, 4ull * ni)); HC(hipMalloc(&right, 4ull * ni));
     HC(hipMalloc(&parent_int, 4ull * ni)); HC(hipMalloc(&parent_leaf, 4ull * n));
-    HC(hipMalloc(&rfirst, 4ull * ni)); HC(hipMalloc(&rlast, 4ull * ni));
-    HC(hipMalloc(&nodes, sizeof(BvhNode) * ni));
+    HC(hipMalloc(&size_int, 4ull * ni)); HC(hipMalloc(&leaf_pos, 4ull * n)); HC(hipMalloc(&node_first, 4ull * ni));
+    HC(hipMalloc(&nodes, sizeof(BvhNode4) * ni));              // a wide node replaces >= 1 binary node
     HC(hipMalloc(&tris, sizeof(TriRec) * n));
     HC(hipMemcpyAsync(bounds, h_bounds, sizeof(h_bounds), hipMemcpyHostToDevice, st));
     HC(hipMemsetAsync(stats, 0, 8, st));
-    HC(hipMemsetAsync(arrive, 0, 4ull * ni, st));
-    HC(hipMemsetAsync(nodes, 0, sizeof(BvhNode) * ni, st));
 
     hipLaunchKernelGGL(k_tri_bounds, dim3(gn), dim3(B), 0, st, flat, n, boxes, bounds);
     if (n <= FOVPT_LEAF_MAX) {
         hipLaunchKernelGGL(k_iota, dim3(1), dim3(64), 0, st, vals_s, n);
-        hipLaunchKernelGGL(k_emit_tiny, dim3(1), dim3(1), 0, st, (int)n, boxes, nodes, stats);
+        hipLaunchKernelGGL(k_emit_tiny, dim3(1), dim3(1), 0, st, (int)n, boxes, nodes, stats, leaf_pos);
     } else {
+        int root = 0;
         hipLaunchKernelGGL(k_morton, dim3(gn), dim3(B), 0, st, boxes, n, bounds, keys, vals);
         HC(rocprim::radix_sort_pairs(nullptr, temp_bytes, keys, keys_s, vals, vals_s, (size_t)n, 0, 63, st));
         HC(hipMalloc(&temp, temp_bytes));
         HC(rocprim::radix_sort_pairs(temp, temp_bytes, keys, keys_s, vals, vals_s, (size_t)n, 0, 63, st));
         if (!use_ploc) {
+            HC(hipMalloc(&arrive, 4ull * ni));
+            HC(hipMalloc(&rfirst, 4ull * ni)); HC(hipMalloc(&rlast, 4ull * ni));
+            HC(hipMemsetAsync(arrive, 0, 4ull * ni, st));
             hipLaunchKernelGGL(k_hierarchy, dim3(gi), dim3(B), 0, st, keys_s, (int)n, left, right, parent_int, parent_leaf, rfirst, rlast);
             hipLaunchKernelGGL(k_refit, dim3(gn), dim3(B), 0, st, boxes, vals_s, (int)n, left, right, parent_int, parent_leaf, ibox, arrive);
-            hipLaunchKernelGGL(k_emit_nodes, dim3(gi), dim3(B), 0, st, (int)n, left, right, rfirst, rlast, boxes, vals_s, ibox, parent_int, nodes, stats);
+            hipLaunchKernelGGL(k_lbvh_generic, dim3(gn), dim3(B), 0, st, (int)n, rfirst, rlast, size_int, node_first, leaf_pos);
+            root = 0;
         } else {
             HC(hipMalloc(&c_node, 4ull * n)); HC(hipMalloc(&t_node, 4ull * n)); HC(hipMalloc(&nn, 4ull * n));
             HC(hipMalloc(&c_box, sizeof(Box) * n)); HC(hipMalloc(&t_box, sizeof(Box) * n));
             HC(hipMalloc(&valid, 4ull * n)); HC(hipMalloc(&pos, 4ull * n));
-            HC(hipMalloc(&node_counter, 4)); HC(hipMalloc(&size_int, 4ull * ni));
-            HC(hipMalloc(&leaf_pos, 4ull * n)); HC(hipMalloc(&node_first, 4ull * ni)); HC(hipMalloc(&node_depth, 4ull * ni));
+            HC(hipMalloc(&node_counter, 4)); HC(hipMalloc(&node_depth, 4ull * ni));
             HC(hipMalloc(&side_int, ni)); HC(hipMalloc(&side_leaf, n));
             HC(hipMemsetAsync(node_counter, 0, 4, st));
             HC(hipMemsetAsync(side_int, 0, ni, st));
@@ -492,14 +497,28 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
             const uint32_t gall = (2 * n - 1 + B - 1) / B;
             hipLaunchKernelGGL(k_dfs_offsets, dim3(gall), dim3(B), 0, st, (int)n, left, parent_int, parent_leaf, side_int, side_leaf, size_int,
                                leaf_pos, node_first, node_depth);
-            hipLaunchKernelGGL(k_emit_nodes_generic, dim3(gi), dim3(B), 0, st, (int)n, left, right, size_int, node_first, leaf_pos, node_depth,
-                               boxes, vals_s, ibox, nodes, stats);
+            root = (int)n - 2;                                 // the last merge created the root
+        }
+        // ---- 2 -> 4 collapse, one launch per level of the wide tree
+        HC(hipMalloc(&work_a, sizeof(Work4) * ni)); HC(hipMalloc(&work_b, sizeof(Work4) * ni));
+        Work4 w0; w0.node = root; w0.out = 0; w0.depth = 0;
+        HC(hipMemcpyAsync(work_a, &w0, sizeof(w0), hipMemcpyHostToDevice, st));
+        HC(hipMemcpyAsync(counters, h_counters, 8, hipMemcpyHostToDevice, st));
+        uint32_t nwork = 1;
+        int levels = 0;
+        while (nwork > 0) {
+            hipLaunchKernelGGL(k_collapse4, dim3((nwork + B - 1) / B), dim3(B), 0, st, (int)nwork, work_a, work_b, counters, left, right,
+                               size_int, node_first, leaf_pos, boxes, vals_s, ibox, nodes, stats);
+            HC(hipMemcpyAsync(h_counters, counters, 8, hipMemcpyDeviceToHost, st));
+            HC(hipStreamSynchronize(st));
+            nwork = h_counters[1];
+            h_counters[1] = 0;
+            HC(hipMemcpyAsync(counters + 1, &h_counters[1], 4, hipMemcpyHostToDevice, st));
+            Work4* t = work_a; work_a = work_b; work_b = t;
+            if (++levels > 4096) { snprintf(err, errlen, "BVH collapse did not terminate"); goto fail; }
         }
     }
-    if (use_ploc && n > FOVPT_LEAF_MAX)
-        hipLaunchKernelGGL(k_emit_tris_generic, dim3(gn), dim3(B), 0, st, flat, mesh_of_prim, vals_s, leaf_pos, n, tris);
-    else
-        hipLaunchKernelGGL(k_emit_tris, dim3(gn), dim3(B), 0, st, flat, mesh_of_prim, vals_s, n, tris);
+    hipLaunchKernelGGL(k_emit_tris_generic, dim3(gn), dim3(B), 0, st, flat, mesh_of_prim, vals_s, leaf_pos, n, tris);
     HC(hipGetLastError());
     HC(hipMemcpyAsync(h_stats, stats, 8, hipMemcpyDeviceToHost, st));
     HC(hipStreamSynchronize(st));
@@ -507,7 +526,7 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
     out->nodes = nodes; out->tris = tris;
     out->num_nodes = h_stats[1];
     out->max_depth = h_stats[0];
-    out->node_bytes = sizeof(BvhNode) * (size_t)ni;
+    out->node_bytes = sizeof(BvhNode4) * (size_t)h_stats[1];
     out->tri_bytes = sizeof(TriRec) * (size_t)n;
     nodes = nullptr; tris = nullptr;
 fail:
@@ -517,6 +536,6 @@ fail:
     (void)hipFree(parent_leaf); (void)hipFree(rfirst); (void)hipFree(rlast); (void)hipFree(temp); (void)hipFree(nodes); (void)hipFree(tris);
     (void)hipFree(c_node); (void)hipFree(t_node); (void)hipFree(nn); (void)hipFree(c_box); (void)hipFree(t_box); (void)hipFree(valid); (void)hipFree(pos);
     (void)hipFree(node_counter); (void)hipFree(size_int); (void)hipFree(leaf_pos); (void)hipFree(node_first); (void)hipFree(node_depth);
-    (void)hipFree(side_int); (void)hipFree(side_leaf); (void)hipFree(scan_temp);
+    (void)hipFree(side_int); (void)hipFree(side_leaf); (void)hipFree(scan_temp); (void)hipFree(work_a); (void)hipFree(work_b); (void)hipFree(counters);
     return rc;
 }

@@ -44,7 +44,7 @@ struct fovpt_ctx {
     // scene
     bool has_scene = false;
     uint64_t scene_id = 0;
-    BvhNode* nodes = nullptr;
+    BvhNode4* nodes = nullptr;
     TriRec* tris = nullptr;
     DevBuf tri_tc, meshes, textures;
     std::vector<void*> tex_pixels;
@@ -388,9 +388,9 @@ int fovpt_set_scene(fovpt_ctx* c, const fovpt_mesh_desc* meshes, int num_meshes,
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(d_flat); (void)hipFree(d_mesh_of);
     if (be != hipSuccess) return fail(c, FOVPT_E_DEVICE, "LBVH build: %s", errbuf);
-    if (br.max_depth > FOVPT_STACK_LDS + FOVPT_STACK_SPILL) {
+    if (3 * br.max_depth + 1 > FOVPT_STACK_LDS + FOVPT_STACK_SPILL) {       // a wide node leaves at most 3 entries behind
         (void)hipFree(br.nodes); (void)hipFree(br.tris);
-        return fail(c, FOVPT_E_BVH_DEPTH, "hierarchy depth %u exceeds the traversal stack (%d)", br.max_depth, FOVPT_STACK_LDS + FOVPT_STACK_SPILL);
+        return fail(c, FOVPT_E_BVH_DEPTH, "hierarchy depth %u needs more than the %d traversal stack entries", br.max_depth, FOVPT_STACK_LDS + FOVPT_STACK_SPILL);
     }
     c->nodes = br.nodes; c->tris = br.tris;
     c->num_tris = (uint32_t)ntri;

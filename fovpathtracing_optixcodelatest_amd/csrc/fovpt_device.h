@@ -10,7 +10,7 @@
 #define FOVPT_WAVE 64
 #define FOVPT_BLOCK 256
 #define FOVPT_LEAF_MAX 4          // triangles per BVH leaf
-#define FOVPT_STACK_LDS 16        // traversal stack entries kept in LDS per lane
+#define FOVPT_STACK_LDS 16        // traversal stack entries kept in LDS per lane (a wide node pushes up to 3)
 #define FOVPT_STACK_SPILL 48      // deeper entries go to a per-lane slice in HBM
 #define FOVPT_MAX_PASSES 3
 #define FOVPT_MAX_ITERS 63         // wavefront iterations per frame (max_depth + catcher pass-throughs)
@@ -28,16 +28,17 @@ struct alignas(16) TriRec {
 };                                // 48 B
 static_assert(sizeof(TriRec) == 48, "TriRec");
 
-// BVH2 node carrying both children's boxes (one 64-B line per visit).
-// child >= 0: internal node index;  child < 0: leaf, ~child = (first_tri << 3) | (count-1).
-struct alignas(16) BvhNode {
-    float lo0x, lo0y, lo0z, hi0x;
-    float hi0y, hi0z, lo1x, lo1y;
-    float lo1z, hi1x, hi1y, hi1z;
-    int32_t c0, c1;
-    uint32_t pad0, pad1;
-};                                // 64 B
-static_assert(sizeof(BvhNode) == 64, "BvhNode");
+// 4-wide BVH node, SoA over the children so one lane tests the four boxes with straight-line code
+// (eight 16-byte loads per visit).  child >= 0: index of a wide node; child < 0: leaf,
+// ~child = (first_tri << 3) | (count-1).  An unused slot holds the degenerate box lo = hi = +inf,
+// which no ray passes.
+struct alignas(16) BvhNode4 {
+    float lox[4], loy[4], loz[4];
+    float hix[4], hiy[4], hiz[4];
+    int32_t child[4];
+    uint32_t pad[4];
+};                                // 128 B
+static_assert(sizeof(BvhNode4) == 128, "BvhNode4");
 
 struct TexDev {
     const uint32_t* px;
@@ -51,7 +52,7 @@ struct MeshDev {                  // the SBT record of the reference (LaunchPara
 };                                // 112 B
 
 struct SceneView {
-    const BvhNode* nodes;
+    const BvhNode4* nodes;
     const TriRec* tris;           // leaf order
     const float2* tri_tc;         // 3 per global primitive id (or null)
     const MeshDev* meshes;
@@ -121,9 +122,9 @@ struct Counters {       // device-resident, zeroed per frame except the stats bl
 
 // ---- launchers implemented in wavefront.hip / bvh_build.hip -------------------------------
 struct BvhBuildResult {
-    BvhNode* nodes;
+    BvhNode4* nodes;
     TriRec* tris;
-    uint32_t num_nodes;           // allocated node slots (n-1 Karras nodes, sparse after collapse)
+    uint32_t num_nodes;           // wide nodes emitted (breadth-first order, root = 0)
     uint32_t max_depth;
     size_t node_bytes, tri_bytes;
 };

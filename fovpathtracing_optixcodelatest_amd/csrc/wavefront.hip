@@ -532,6 +532,18 @@ __device__ inline TriRec load_tri(const TriRec* __restrict__ tris, uint32_t i)
 #define TMIN 0.01f     // deviceProgram.cu:41
 #define TMAX 1e16f     // deviceProgram.cu:42
 
+// sort two (distance, child) pairs so that the first is not farther than the second
+__device__ inline void cswap(float& ta, int& ca, float& tb, int& cb)
+{
+    const bool sw = tb < ta;
+    const float t = sw ? tb : ta, u = sw ? ta : tb;
+    const int c = sw ? cb : ca, d = sw ? ca : cb;
+    ta = t; tb = u; ca = c; cb = d;
+}
+
+// While-while traversal of the 4-wide BVH.  Closest-hit rays visit children front to back (sorting
+// network on the four entry distances) and shrink the interval to the best hit; any-hit rays take the
+// children in storage order and leave at the first front-facing candidate.
 template <bool ANY_HIT>
 __device__ inline void traverse(const SceneView& sc, const RayT& r, Stack& st, float& best_t, float& best_u, float& best_v,
                                 uint32_t& best_pos, uint32_t& best_prim, bool& occluded)
@@ -539,26 +551,42 @@ __device__ inline void traverse(const SceneView& sc, const RayT& r, Stack& st, f
     st.sp = 0;
     int cur = 0;                       // root
     for (;;) {
-        // ---- internal nodes
+        // ---- wide internal nodes
         while (cur >= 0) {
             const float4* np = (const float4*)(sc.nodes + cur);
-            const float4 n0 = np[0], n1 = np[1], n2 = np[2];
-            const int4 n3 = ((const int4*)np)[3];
+            const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
+            const int4 ch = ((const int4*)np)[6];
             const float lim = ANY_HIT ? TMAX : fminf(TMAX, best_t * 1.000001f);
-            float t0, t1;
-            const bool h0 = box_hit(r, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, TMIN, lim, t0);
-            const bool h1 = box_hit(r, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, TMIN, lim, t1);
-            if (h0 && h1) {
-                const bool swap = t1 < t0;
-                st.push(swap ? n3.x : n3.y);
-                cur = swap ? n3.y : n3.x;
-            } else if (h0) {
-                cur = n3.x;
-            } else if (h1) {
-                cur = n3.y;
-            } else {
+            float t0, t1, t2, t3;
+            const bool h0 = box_hit(r, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, TMIN, lim, t0);
+            const bool h1 = box_hit(r, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, TMIN, lim, t1);
+            const bool h2 = box_hit(r, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, TMIN, lim, t2);
+            const bool h3 = box_hit(r, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, TMIN, lim, t3);
+            if (!(h0 || h1 || h2 || h3)) {
                 if (st.sp == 0) return;
                 cur = st.pop();
+                continue;
+            }
+            if (ANY_HIT) {
+                // order does not matter: continue with the first hit child, stack the others
+                int next = 0;
+                bool have = false;
+                if (h0) { next = ch.x; have = true; }
+                if (h1) { if (have) st.push(ch.y); else { next = ch.y; have = true; } }
+                if (h2) { if (have) st.push(ch.z); else { next = ch.z; have = true; } }
+                if (h3) { if (have) st.push(ch.w); else { next = ch.w; have = true; } }
+                cur = next;
+            } else {
+                float a = h0 ? t0 : INFINITY, b = h1 ? t1 : INFINITY, c = h2 ? t2 : INFINITY, d = h3 ? t3 : INFINITY;
+                int ca = ch.x, cb = ch.y, cc = ch.z, cd = ch.w;
+                cswap(a, ca, b, cb); cswap(c, cc, d, cd);
+                cswap(a, ca, c, cc); cswap(b, cb, d, cd);
+                cswap(b, cb, c, cc);
+                // a <= b <= c <= d; misses carry +inf and sort to the end.  Farthest first onto the stack.
+                if (d < INFINITY) st.push(cd);
+                if (c < INFINITY) st.push(cc);
+                if (b < INFINITY) st.push(cb);
+                cur = ca;
             }
         }
         // ---- leaf
