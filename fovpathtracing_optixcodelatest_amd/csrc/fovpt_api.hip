@@ -636,6 +636,19 @@ int fovpt_camera_uvw(const fovpt_float3* eye, const fovpt_float3* lookat, const 
     return FOVPT_OK;
 }
 
+// test/diagnostic hook: device address and size of an internal buffer
+int fovpt_debug_buffer(fovpt_ctx* c, const char* name, void** ptr, size_t* bytes)
+{
+    if (!c || !name || !ptr || !bytes) return FOVPT_E_INVALID;
+    struct { const char* n; DevBuf* b; } tab[] = {
+        {"sq_o", &c->sq_o}, {"sq_d", &c->sq_d}, {"sq_vis", &c->sq_vis}, {"sq_occ", &c->sq_occ}, {"counters", &c->counters},
+        {"hit", &c->s_hit}, {"queue_a", &c->q_a}, {"queue_b", &c->q_b}, {"ray_o", &c->s_ray_o}, {"ray_d", &c->s_ray_d},
+    };
+    for (auto& t : tab)
+        if (strcmp(t.n, name) == 0) { *ptr = t.b->p; *bytes = t.b->bytes; return FOVPT_OK; }
+    return fail(c, FOVPT_E_INVALID, "unknown debug buffer %s", name);
+}
+
 int fovpt_debug_math(fovpt_ctx* c, int op, const float* a, const float* b, float* out, size_t n)
 {
     if (!c || !a || !out) return FOVPT_E_INVALID;

@@ -9,7 +9,9 @@
 
 #define FOVPT_WAVE 64
 #define FOVPT_BLOCK 256
-#define FOVPT_LEAF_MAX 4          // triangles per BVH leaf
+#ifndef FOVPT_LEAF_MAX
+#define FOVPT_LEAF_MAX 4          // triangles per BVH leaf (<= 8: three bits in the leaf code)
+#endif
 #define FOVPT_STACK_LDS 16        // traversal stack entries kept in LDS per lane (a wide node pushes up to 3)
 #define FOVPT_STACK_SPILL 48      // deeper entries go to a per-lane slice in HBM
 #define FOVPT_MAX_PASSES 3

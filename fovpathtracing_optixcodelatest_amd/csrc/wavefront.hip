@@ -23,6 +23,14 @@
 #include "fovpt_device.h"
 #include "../../include/fovpt_detmath.h"
 
+#ifndef FOVPT_V_STEPSTAT
+#define FOVPT_V_STEPSTAT 0
+#endif
+// waves per SIMD the traversal kernel is compiled for (caps VGPRs at 64); measured best
+#ifndef FOVPT_V_WAVES
+#define FOVPT_V_WAVES 8
+#endif
+
 namespace {
 
 // ------------------------------------------------------------------------------------------
@@ -466,7 +474,10 @@ struct Stack {
     __device__ inline int pop()
     {
         sp--;
-        return sp < FOVPT_STACK_LDS ? lds[sp * FOVPT_BLOCK] : spill[(size_t)(sp - FOVPT_STACK_LDS) * stride];
+        // the LDS read is unconditional (ds_read, no flat load); the spill slice is the rare path
+        int v = lds[(sp < FOVPT_STACK_LDS ? sp : FOVPT_STACK_LDS - 1) * FOVPT_BLOCK];
+        if (sp >= FOVPT_STACK_LDS) v = spill[(size_t)(sp - FOVPT_STACK_LDS) * stride];
+        return v;
     }
 };
 
@@ -550,9 +561,18 @@ __device__ inline void traverse(const SceneView& sc, const RayT& r, Stack& st, f
 {
     st.sp = 0;
     int cur = 0;                       // root
+#if FOVPT_V_STEPSTAT
+    uint32_t steps = 0;
+#define STEP_RETURN do { best_u = __uint_as_float(steps); return; } while (0)
+#else
+#define STEP_RETURN return
+#endif
     for (;;) {
         // ---- wide internal nodes
         while (cur >= 0) {
+#if FOVPT_V_STEPSTAT
+            steps++;
+#endif
             const float4* np = (const float4*)(sc.nodes + cur);
             const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
             const int4 ch = ((const int4*)np)[6];
@@ -563,12 +583,13 @@ __device__ inline void traverse(const SceneView& sc, const RayT& r, Stack& st, f
             const bool h2 = box_hit(r, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, TMIN, lim, t2);
             const bool h3 = box_hit(r, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, TMIN, lim, t3);
             if (!(h0 || h1 || h2 || h3)) {
-                if (st.sp == 0) return;
+                if (st.sp == 0) STEP_RETURN;
                 cur = st.pop();
                 continue;
             }
             if (ANY_HIT) {
-                // order does not matter: continue with the first hit child, stack the others
+                // continue with the first hit child, stack the others (sorting them by distance was
+                // measured slower: an occluder anywhere ends the ray)
                 int next = 0;
                 bool have = false;
                 if (h0) { next = ch.x; have = true; }
@@ -599,13 +620,16 @@ __device__ inline void traverse(const SceneView& sc, const RayT& r, Stack& st, f
                 if (!tri_hit(r, T, t, u, v, det)) continue;
                 if (!(t > TMIN && t < TMAX)) continue;
                 if (ANY_HIT) {
-                    if (det > 0.0f) { occluded = true; return; }      // front face: counter-clockwise seen from the origin
+                    if (det > 0.0f) { occluded = true; STEP_RETURN; }      // front face: counter-clockwise seen from the origin
                 } else if (t < best_t || (t == best_t && T.prim < best_prim)) {
                     best_t = t; best_u = u; best_v = v; best_pos = first + k; best_prim = T.prim;
                 }
             }
-            if (st.sp == 0) return;
+            if (st.sp == 0) STEP_RETURN;
             cur = st.pop();
+#if FOVPT_V_STEPSTAT
+            steps += 0x10000u;
+#endif
         }
     }
 }
@@ -616,7 +640,7 @@ __device__ inline void traverse(const SceneView& sc, const RayT& r, Stack& st, f
 // thus run beside the many closest-hit rays of the next instead of leaving the chip 60 % empty.
 // (Dynamic work fetching was measured and rejected: with <= 2 rays per resident lane per launch a
 // returning atomic per wave costs more than the imbalance it removes -- DESIGN.md section 4.)
-__global__ __launch_bounds__(FOVPT_BLOCK) void k_traverse(SceneView sc, PathState ps, const uint32_t* __restrict__ queue, ShadowQueue sq,
+__global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneView sc, PathState ps, const uint32_t* __restrict__ queue, ShadowQueue sq,
                                                           uint32_t cap, Counters* __restrict__ cnt, int it_closest, int it_shadow,
                                                           int* __restrict__ spill)
 {
@@ -649,6 +673,9 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_traverse(SceneView sc, PathStat
             bool occ = false;
             traverse<true>(sc, r, st, bt, bu, bv, bpos, bprim, occ);
             // the deferred NEE add of SampleLights / SampleShadow (deviceProgram.cu:323-341,367-385)
+#if FOVPT_V_STEPSTAT
+            sq.val_occ[ph].w = bu; sq.val_vis[ph].w = occ ? 1.f : 0.f;
+#endif
             const float4 val = occ ? sq.val_occ[ph] : sq.val_vis[ph];
             const uint32_t slot = __float_as_uint(o.w);
             const uint32_t target = __float_as_uint(d.w);

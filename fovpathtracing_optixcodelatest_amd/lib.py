@@ -10,13 +10,13 @@ from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libfovpt.so")
+SO_PATH = os.environ.get("FOVPT_SO") or os.path.join(CSRC, "libfovpt.so")   # FOVPT_SO: A/B builds of the same library
 
 EXPORTS = [
     "fovpt_create", "fovpt_destroy", "fovpt_last_error", "fovpt_set_scene", "fovpt_set_probe",
     "fovpt_resize", "fovpt_get_config", "fovpt_set_config", "fovpt_launch", "fovpt_render",
     "fovpt_synchronize", "fovpt_download", "fovpt_get_stats", "fovpt_reset_stats", "fovpt_stream",
-    "fovpt_probe_build_cdf", "fovpt_camera_uvw", "fovpt_debug_math",
+    "fovpt_probe_build_cdf", "fovpt_camera_uvw", "fovpt_debug_math", "fovpt_debug_buffer",
 ]
 
 
@@ -70,6 +70,7 @@ def load():
     L.fovpt_camera_uvw.argtypes = [C.POINTER(abi.Float3), C.POINTER(abi.Float3), C.POINTER(abi.Float3),
                                    C.c_float, C.c_float, C.POINTER(abi.Float3), C.POINTER(abi.Float3), C.POINTER(abi.Float3)]
     L.fovpt_debug_math.argtypes = [vp, i32, vp, vp, vp, sz]
+    L.fovpt_debug_buffer.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(sz)]
     for name in EXPORTS:
         if name not in ("fovpt_destroy", "fovpt_last_error", "fovpt_stream"):
             getattr(L, name).restype = i32
