@@ -38,7 +38,10 @@ struct EventPair { hipEvent_t a, b; int kind; };   // kind: 0 gen, 1 trace, 2 sh
 struct fovpt_ctx {
     int device = 0;
     int num_cus = 256;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // main chain: generate, closest-hit traversal, shade, resolve
+    hipStream_t shadow_stream = nullptr;   // occlusion rays of every bounce, off the critical path
+    hipEvent_t ev_shade[FOVPT_MAX_ITERS + 1] = {};
+    hipEvent_t ev_shadow[FOVPT_MAX_ITERS + 1] = {};
     std::string err;
     fovpt_config cfg;
     // scene
@@ -54,9 +57,9 @@ struct fovpt_ctx {
     // frame buffers (resize)
     DevBuf fb_frame, fb_accum, fb_color, fb_normal, fb_albedo;
     // wavefront state
-    DevBuf s_ray_o, s_ray_d, s_thr, s_rng, s_hit, s_direct, s_indirect, s_alpha, s_backplate;
-    DevBuf q_a, q_b, sq_o, sq_d, sq_vis, sq_occ, counters, spill;
-    int grid = 2048;
+    DevBuf s_ray_o, s_ray_d, s_thr, s_rng, s_hit, s_rad, s_alpha, s_backplate;
+    DevBuf q_a, q_b, sq_o[2], sq_d[2], sq_vis[2], sq_occ[2], counters, spill, spill_shadow;
+    int grid = 2048, grid_shadow = 1024;
     // stats
     fovpt_stats stats;
     std::vector<EventPair> pending;
@@ -101,14 +104,14 @@ hipEvent_t get_event(fovpt_ctx* c)
 }
 
 struct Timed {
-    fovpt_ctx* c; int kind; hipEvent_t a = nullptr, b = nullptr;
-    Timed(fovpt_ctx* c_, int k) : c(c_), kind(k)
+    fovpt_ctx* c; int kind; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
+    Timed(fovpt_ctx* c_, int k, hipStream_t s = nullptr) : c(c_), kind(k), st(s ? s : c_->stream)
     {
-        if (c->cfg.profile) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, c->stream); }
+        if (c->cfg.profile) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, st); }
     }
     ~Timed()
     {
-        if (c->cfg.profile) { (void)hipEventRecord(b, c->stream); EventPair p = {a, b, kind}; c->pending.push_back(p); }
+        if (c->cfg.profile) { (void)hipEventRecord(b, st); EventPair p = {a, b, kind}; c->pending.push_back(p); }
     }
 };
 
@@ -145,19 +148,24 @@ int ensure_state(fovpt_ctx* c, size_t slots, size_t launches)
     const size_t v = 16;
     HIPCHK(c, c->s_ray_o.reserve(slots * v)); HIPCHK(c, c->s_ray_d.reserve(slots * v));
     HIPCHK(c, c->s_thr.reserve(slots * v)); HIPCHK(c, c->s_rng.reserve(slots * v));
-    HIPCHK(c, c->s_hit.reserve(slots * v)); HIPCHK(c, c->s_direct.reserve(slots * v));
-    HIPCHK(c, c->s_indirect.reserve(slots * v)); HIPCHK(c, c->s_alpha.reserve(slots * v));
+    HIPCHK(c, c->s_hit.reserve(slots * v)); HIPCHK(c, c->s_alpha.reserve(slots * v));
+    HIPCHK(c, c->s_rad.reserve(slots * v * (size_t)c->cfg.max_depth));
     HIPCHK(c, c->s_backplate.reserve(launches * v));
-    // sharded queues: FOVPT_SHARDS regions of `slots` entries each (memory is laid out for 288 GB)
+    // sharded queues: FOVPT_SHARDS regions of `slots` entries each (memory is laid out for 288 GB);
+    // the shadow queue is double-buffered because bounce it's occlusion rays may still be in flight
+    // on the shadow stream while bounce it+1 is being shaded
     const size_t qn = slots * FOVPT_SHARDS;
     HIPCHK(c, c->q_a.reserve(qn * 4)); HIPCHK(c, c->q_b.reserve(qn * 4));
-    HIPCHK(c, c->sq_o.reserve(qn * v)); HIPCHK(c, c->sq_d.reserve(qn * v));
-    HIPCHK(c, c->sq_vis.reserve(qn * v)); HIPCHK(c, c->sq_occ.reserve(qn * v));
+    for (int k = 0; k < 2; k++) {
+        HIPCHK(c, c->sq_o[k].reserve(qn * v)); HIPCHK(c, c->sq_d[k].reserve(qn * v));
+        HIPCHK(c, c->sq_vis[k].reserve(qn * v)); HIPCHK(c, c->sq_occ[k].reserve(qn * v));
+    }
     if (!c->counters.p) {
         HIPCHK(c, c->counters.reserve(sizeof(Counters)));
         HIPCHK(c, hipMemsetAsync(c->counters.p, 0, sizeof(Counters), c->stream));
     }
     HIPCHK(c, c->spill.reserve((size_t)c->grid * FOVPT_BLOCK * FOVPT_STACK_SPILL * sizeof(int)));
+    HIPCHK(c, c->spill_shadow.reserve((size_t)c->grid_shadow * FOVPT_BLOCK * FOVPT_STACK_SPILL * sizeof(int)));
     return FOVPT_OK;
 }
 
@@ -207,10 +215,13 @@ int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passe
 
     PathState ps;
     ps.ray_o = (float4*)c->s_ray_o.p; ps.ray_d = (float4*)c->s_ray_d.p; ps.thr = (float4*)c->s_thr.p;
-    ps.rng = (uint4*)c->s_rng.p; ps.hit = (float4*)c->s_hit.p; ps.direct = (float4*)c->s_direct.p;
-    ps.indirect = (float4*)c->s_indirect.p; ps.alpha = (float4*)c->s_alpha.p; ps.backplate = (float4*)c->s_backplate.p;
-    ShadowQueue sq;
-    sq.o = (float4*)c->sq_o.p; sq.d = (float4*)c->sq_d.p; sq.val_vis = (float4*)c->sq_vis.p; sq.val_occ = (float4*)c->sq_occ.p;
+    ps.rng = (uint4*)c->s_rng.p; ps.hit = (float4*)c->s_hit.p; ps.rad = (float4*)c->s_rad.p; ps.stride = (size_t)slots;
+    ps.alpha = (float4*)c->s_alpha.p; ps.backplate = (float4*)c->s_backplate.p;
+    ShadowQueue sq[2];
+    for (int k = 0; k < 2; k++) {
+        sq[k].o = (float4*)c->sq_o[k].p; sq[k].d = (float4*)c->sq_d[k].p;
+        sq[k].val_vis = (float4*)c->sq_vis[k].p; sq[k].val_occ = (float4*)c->sq_occ[k].p;
+    }
     SceneView sc;
     sc.nodes = c->nodes; sc.tris = c->tris; sc.tri_tc = (const float2*)c->tri_tc.p;
     sc.meshes = (const MeshDev*)c->meshes.p; sc.textures = (const TexDev*)c->textures.p;
@@ -218,7 +229,7 @@ int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passe
     Counters* cnt = (Counters*)c->counters.p;
     uint32_t* qa = (uint32_t*)c->q_a.p;
     uint32_t* qb = (uint32_t*)c->q_b.p;
-    hipStream_t st = c->stream;
+    hipStream_t st = c->stream, ss = c->shadow_stream;
 
     HIPCHK(c, hipMemsetAsync(cnt, 0, offsetof(Counters, stat_radiance), st));
     const int grid = c->grid;
@@ -228,14 +239,22 @@ int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passe
     // pass-throughs (which do not advance depth) when the scene holds a catcher
     int iters = c->cfg.max_depth + (c->any_catcher ? 1 + 24 : 0);
     if (iters > FOVPT_MAX_ITERS) iters = FOVPT_MAX_ITERS;
-    // launch 0 traces the camera rays; launch it+1 traces the shadow rays of bounce `it` together
-    // with the radiance rays of bounce `it+1`
-    { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qa, sq, cap, cnt, 0, -1, (int*)c->spill.p, grid); }
+    // Main chain (stream `st`):    generate, closest(0), shade(0), closest(1), shade(1), ... resolve
+    // Shadow chain (stream `ss`):  occlusion(it) as soon as shade(it) has queued its rays.
+    // Every radiance cell has one writer, so the only joins are: shade(it+2) reuses the shadow queue
+    // buffer of bounce it, and resolve needs everything.
+    { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qa, sq[0], cap, cnt, 0, -1, (int*)c->spill.p, grid); }
     for (int it = 0; it < iters; it++) {
-        { Timed t(c, 2); fovpt_launch_shade(st, fd, sc, ps, qa, qb, sq, cap, cnt, it, grid); }
-        { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qb, sq, cap, cnt, it + 1 < iters ? it + 1 : -1, it, (int*)c->spill.p, grid); }
+        if (it >= 2) HIPCHK(c, hipStreamWaitEvent(st, c->ev_shadow[it - 2], 0));
+        { Timed t(c, 2); fovpt_launch_shade(st, fd, sc, ps, qa, qb, sq[it & 1], cap, cnt, it, grid); }
+        HIPCHK(c, hipEventRecord(c->ev_shade[it], st));
+        HIPCHK(c, hipStreamWaitEvent(ss, c->ev_shade[it], 0));
+        { Timed t(c, 3, ss); fovpt_launch_traverse(ss, sc, ps, qb, sq[it & 1], cap, cnt, -1, it, (int*)c->spill_shadow.p, c->grid_shadow); }
+        HIPCHK(c, hipEventRecord(c->ev_shadow[it], ss));
+        if (it + 1 < iters) { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qb, sq[0], cap, cnt, it + 1, -1, (int*)c->spill.p, grid); }
         uint32_t* tmp = qa; qa = qb; qb = tmp;
     }
+    for (int it = iters >= 2 ? iters - 2 : 0; it < iters; it++) HIPCHK(c, hipStreamWaitEvent(st, c->ev_shadow[it], 0));
     { Timed t(c, 4); fovpt_launch_resolve(st, fd, ps); }
     HIPCHK(c, hipGetLastError());
     return FOVPT_OK;
@@ -277,8 +296,14 @@ int fovpt_create(fovpt_ctx** out, int device)
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
     c->grid = c->num_cus * 8;                 // 8 blocks of 256 = 32 waves per CU, grid-stride over the queues
+    c->grid_shadow = c->num_cus * 4;
     e = hipStreamCreate(&c->stream);
-    if (e != hipSuccess) { delete c; return fail(nullptr, FOVPT_E_DEVICE, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    if (e == hipSuccess) e = hipStreamCreate(&c->shadow_stream);
+    for (int k = 0; k <= FOVPT_MAX_ITERS && e == hipSuccess; k++) {
+        e = hipEventCreateWithFlags(&c->ev_shade[k], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_shadow[k], hipEventDisableTiming);
+    }
+    if (e != hipSuccess) { delete c; return fail(nullptr, FOVPT_E_DEVICE, "stream/event creation: %s", hipGetErrorString(e)); }
     *out = c;
     return FOVPT_OK;
 }
@@ -288,15 +313,22 @@ void fovpt_destroy(fovpt_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->shadow_stream);
     drain_events(c);
     for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
+    for (int k = 0; k <= FOVPT_MAX_ITERS; k++) {
+        if (c->ev_shade[k]) (void)hipEventDestroy(c->ev_shade[k]);
+        if (c->ev_shadow[k]) (void)hipEventDestroy(c->ev_shadow[k]);
+    }
     free_scene(c);
     DevBuf* bufs[] = {&c->tri_tc, &c->meshes, &c->textures, &c->pr_data, &c->pr_pdfx, &c->pr_cdfx, &c->pr_pdfy, &c->pr_cdfy,
                       &c->fb_frame, &c->fb_accum, &c->fb_color, &c->fb_normal, &c->fb_albedo,
-                      &c->s_ray_o, &c->s_ray_d, &c->s_thr, &c->s_rng, &c->s_hit, &c->s_direct, &c->s_indirect, &c->s_alpha, &c->s_backplate,
-                      &c->q_a, &c->q_b, &c->sq_o, &c->sq_d, &c->sq_vis, &c->sq_occ, &c->counters, &c->spill};
+                      &c->s_ray_o, &c->s_ray_d, &c->s_thr, &c->s_rng, &c->s_hit, &c->s_rad, &c->s_alpha, &c->s_backplate,
+                      &c->q_a, &c->q_b, &c->sq_o[0], &c->sq_d[0], &c->sq_vis[0], &c->sq_occ[0],
+                      &c->sq_o[1], &c->sq_d[1], &c->sq_vis[1], &c->sq_occ[1], &c->counters, &c->spill, &c->spill_shadow};
     for (DevBuf* b : bufs) b->release();
     (void)hipStreamDestroy(c->stream);
+    (void)hipStreamDestroy(c->shadow_stream);
     delete c;
 }
 
@@ -309,6 +341,7 @@ int fovpt_set_scene(fovpt_ctx* c, const fovpt_mesh_desc* meshes, int num_meshes,
     if (!meshes || num_meshes <= 0) return fail(c, FOVPT_E_INVALID, "scene needs at least one mesh");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
     free_scene(c);
     uint64_t ntri = 0;
     bool any_tc = false;
@@ -412,6 +445,7 @@ int fovpt_set_probe(fovpt_ctx* c, int width, int height, const fovpt_float4* dat
         return fail(c, FOVPT_E_INVALID, "Probe Data is not valid");                         // Probe.h:104-105
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
     const size_t n = (size_t)width * height;
     HIPCHK(c, c->pr_pdfx.reserve(n * 4)); HIPCHK(c, c->pr_cdfx.reserve(n * 4));
     HIPCHK(c, c->pr_pdfy.reserve((size_t)height * 4)); HIPCHK(c, c->pr_cdfy.reserve((size_t)height * 4));
@@ -437,6 +471,7 @@ int fovpt_resize(fovpt_ctx* c, int width, int height, fovpt_frame_ptrs* out)
     if (width < 0 || height < 0 || !out) return fail(c, FOVPT_E_INVALID, "bad resize arguments");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
     const size_t n = (size_t)width * height;
     HIPCHK(c, c->fb_frame.reserve(n * 4)); HIPCHK(c, c->fb_accum.reserve(n * 16));
     HIPCHK(c, c->fb_color.reserve(n * 16)); HIPCHK(c, c->fb_normal.reserve(n * 16)); HIPCHK(c, c->fb_albedo.reserve(n * 16));
@@ -543,6 +578,7 @@ int fovpt_synchronize(fovpt_ctx* c)
     if (!c) return FOVPT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
     return FOVPT_OK;
 }
 
@@ -551,6 +587,7 @@ int fovpt_download(fovpt_ctx* c, const void* device_src, void* host_dst, size_t 
     if (!c || !device_src || !host_dst) return FOVPT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
     HIPCHK(c, hipMemcpy(host_dst, device_src, n_bytes, hipMemcpyDeviceToHost));
     return FOVPT_OK;
 }
@@ -560,6 +597,7 @@ int fovpt_get_stats(fovpt_ctx* c, fovpt_stats* out)
     if (!c || !out) return FOVPT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
     drain_events(c);
     if (c->counters.p) {
         Counters h;
@@ -575,6 +613,7 @@ int fovpt_reset_stats(fovpt_ctx* c)
     if (!c) return FOVPT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
     drain_events(c);
     if (c->counters.p) HIPCHK(c, hipMemset((char*)c->counters.p + offsetof(Counters, stat_radiance), 0, sizeof(Counters) - offsetof(Counters, stat_radiance)));
     c->stats.radiance_rays = c->stats.shadow_rays = c->stats.paths = c->stats.frames = 0;
@@ -641,7 +680,7 @@ int fovpt_debug_buffer(fovpt_ctx* c, const char* name, void** ptr, size_t* bytes
 {
     if (!c || !name || !ptr || !bytes) return FOVPT_E_INVALID;
     struct { const char* n; DevBuf* b; } tab[] = {
-        {"sq_o", &c->sq_o}, {"sq_d", &c->sq_d}, {"sq_vis", &c->sq_vis}, {"sq_occ", &c->sq_occ}, {"counters", &c->counters},
+        {"sq_o", &c->sq_o[1]}, {"sq_d", &c->sq_d[1]}, {"sq_vis", &c->sq_vis[1]}, {"sq_occ", &c->sq_occ[1]}, {"counters", &c->counters},
         {"hit", &c->s_hit}, {"queue_a", &c->q_a}, {"queue_b", &c->q_b}, {"ray_o", &c->s_ray_o}, {"ray_d", &c->s_ray_d},
     };
     for (auto& t : tab)
@@ -661,6 +700,7 @@ int fovpt_debug_math(fovpt_ctx* c, int op, const float* a, const float* b, float
     else HIPCHK(c, hipMemset(db, 0, n * 4));
     fovpt_launch_math(c->stream, op, da, db, dout, n);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
     HIPCHK(c, hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
     (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
     return FOVPT_OK;

@@ -445,8 +445,8 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, Pat
             ps.ray_d[slot] = f4(dir, 0.f);
             ps.thr[slot] = make_float4(1.f, 1.f, 1.f, 1.0f);                    // pathThroughput, rayEta
             ps.rng[slot] = make_uint4(rng.s1, rng.s2, 0u, 0u);                  // stateFlags 0, depth 0
-            ps.direct[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
-            ps.indirect[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int dd = 0; dd < fd.max_depth; dd++)                          // directLight / indirectLight terms, :450-451
+                ps.rad[(size_t)dd * ps.stride + slot] = make_float4(0.f, 0.f, 0.f, 0.f);
             ps.alpha[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (s == P.spp - 1) {                                               // backplate of the last sample, :495
                 float u, v;
@@ -677,12 +677,12 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
             sq.val_occ[ph].w = bu; sq.val_vis[ph].w = occ ? 1.f : 0.f;
 #endif
             const float4 val = occ ? sq.val_occ[ph] : sq.val_vis[ph];
+            // every (slot, depth) cell has exactly one writer, so this is a plain store and the shadow
+            // rays of a bounce may run at any time before resolve (own stream, see fovpt_api.hip)
             const uint32_t slot = __float_as_uint(o.w);
             const uint32_t target = __float_as_uint(d.w);
-            float4* acc = target == 0u ? ps.direct : (target == 1u ? ps.indirect : ps.alpha);
-            float4 a = acc[slot];
-            a.x += val.x; a.y += val.y; a.z += val.z;
-            acc[slot] = a;
+            float4* cell = target == 0xffffffffu ? ps.alpha + slot : ps.rad + ((size_t)target * ps.stride + slot);
+            *cell = make_float4(val.x, val.y, val.z, 0.f);
         } else {
             const uint32_t slot = queue[mq.phys(i - n_sh_pad, cap)];
             RayT r;
@@ -722,12 +722,7 @@ __device__ inline float4 tex2d(const TexDev& T, float u, float v)
                        w00 * c00.w + w10 * c10.w + w01 * c01.w + w11 * c11.w);
 }
 
-__device__ inline void acc_add(float4* acc, uint32_t slot, const V3& v)
-{
-    float4 a = acc[slot];
-    a.x += v.x; a.y += v.y; a.z += v.z;
-    acc[slot] = a;
-}
+#define FLAG_ALPHA_ONE 4u      // prd.alpha = make_float3(1) happened (deviceProgram.cu:689)
 
 __global__ __launch_bounds__(FOVPT_BLOCK) void k_shade(const FrameDev fd, SceneView sc, PathState ps,
                                                        const uint32_t* __restrict__ queue_in, uint32_t* __restrict__ queue_out,
@@ -774,8 +769,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_shade(const FrameDev fd, SceneV
                     // the reference's discarded last segment (:515).  It is only traced here when the
                     // scene holds a shadow catcher; a catcher hit is always a pass-through at this
                     // depth (SECONDARY is set), so this is a plain hit whose one lasting effect is :689
-                    ps.alpha[slot] = make_float4(1.f, 1.f, 1.f, 0.f);
-                    flags |= FLAG_DONE;
+                    flags |= FLAG_ALPHA_ONE | FLAG_DONE;
                 } else {
                     float4 t4 = ps.thr[slot];
                     V3 thr = v3(t4);
@@ -831,32 +825,31 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_shade(const FrameDev fd, SceneV
                     basis_from_vector(N, bu, bv);
                     V3 bsdfDir = v3(0.f);
                     const float bsdfPdf = bsdf_sample(mat, rayEta, outEta, bu, bv, N, wo, bsdfDir, rng);   // :706
-                    if (alpha_set_one) ps.alpha[slot] = make_float4(1.f, 1.f, 1.f, 0.f);  // :689 (kept even when DONE)
+                    if (alpha_set_one) flags |= FLAG_ALPHA_ONE;                            // :689 (kept even when DONE)
                     const bool same = rad_vis.x == rad_occ.x && rad_vis.y == rad_occ.y && rad_vis.z == rad_occ.z
                                    && alpha_vis.x == alpha_occ.x && alpha_vis.y == alpha_occ.y && alpha_vis.z == alpha_occ.z;
                     if (catcher) {
-                        // alpha += thr * shadowSample happens regardless of what follows (:693)
-                        if (same) acc_add(ps.alpha, slot, alpha_occ);
+                        // alpha += thr * shadowSample happens regardless of what follows (:693); alpha is still
+                        // (0,0,0) here because only a primary hit gets this far on a catcher
+                        if (same) ps.alpha[slot] = f4(v3(0.f) + alpha_occ, 0.f);
                         else {
                             want_shadow = true;
-                            sh_o = f4(P, __uint_as_float(slot)); sh_d = f4(wi, __uint_as_float(2u));
-                            sh_vis = f4(alpha_vis, 0.f); sh_occ = f4(alpha_occ, 0.f);
+                            sh_o = f4(P, __uint_as_float(slot)); sh_d = f4(wi, __uint_as_float(0xffffffffu));
+                            sh_vis = f4(v3(0.f) + alpha_vis, 0.f); sh_occ = f4(v3(0.f) + alpha_occ, 0.f);
                         }
                     }
                     if (bsdfPdf <= 0.0f) {                                                 // :708-711
                         flags |= FLAG_DONE;       // radiance of this hit is dropped by the break at :515
                     } else {
-                        // the segment counts: direct (depth 0) or indirect gets prd.radiance (:522-527)
-                        float4* acc = depth == 0 ? ps.direct : ps.indirect;
-                        if (!catcher) {
-                            if (same) acc_add(acc, slot, rad_occ);
-                            else {
-                                want_shadow = true;
-                                sh_o = f4(P, __uint_as_float(slot)); sh_d = f4(wi, __uint_as_float(depth == 0 ? 0u : 1u));
-                                sh_vis = f4(rad_vis, 0.f); sh_occ = f4(rad_occ, 0.f);
-                            }
+                        // the segment counts: prd.radiance becomes the depth-th term of directLight (depth 0) /
+                        // indirectLight (:522-527).  One cell per (slot, depth), summed in order by resolve.
+                        float4* cell = ps.rad + ((size_t)depth * ps.stride + slot);
+                        if (!catcher && !same) {
+                            want_shadow = true;
+                            sh_o = f4(P, __uint_as_float(slot)); sh_d = f4(wi, __uint_as_float((uint32_t)depth));
+                            sh_vis = f4(rad_vis, 0.f); sh_occ = f4(rad_occ, 0.f);
                         } else {
-                            acc_add(acc, slot, rad_occ);
+                            *cell = f4(rad_occ, 0.f);
                         }
                         const V3 f = bsdf_eval(mat, albedo, rayEta, outEta, N, wo, bsdfDir);   // :714
                         if (dot(bsdfDir, N) <= 0.0f) rayEta = outEta;                      // :717-721
@@ -951,9 +944,14 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_resolve(const FrameDev fd, Path
                 const uint32_t s0 = P.slot_base + li * P.spp;
                 V3 result = v3(0.0f), alpha = v3(0.0f);
                 for (uint32_t s = 0; s < P.spp; s++) {                                     // :536-537, in sample order
-                    const V3 d = v3(ps.direct[s0 + s]), in = v3(ps.indirect[s0 + s]);
-                    result = result + (d + in);
-                    alpha = alpha + v3(ps.alpha[s0 + s]);
+                    const uint32_t slot = s0 + s;
+                    const V3 direct = v3(0.0f) + v3(ps.rad[slot]);                            // :523
+                    V3 indirect = v3(0.0f);
+                    for (int dd = 1; dd < fd.max_depth; dd++)                                  // :526, in bounce order
+                        indirect = indirect + v3(ps.rad[(size_t)dd * ps.stride + slot]);
+                    result = result + (direct + indirect);
+                    const bool one = (ps.rng[slot].z & FLAG_ALPHA_ONE) != 0u;
+                    alpha = alpha + (one ? v3(1.0f) : v3(ps.alpha[slot]));
                 }
                 const float sppf = (float)P.spp;
                 { const float inv = 1.0f / sppf; alpha = alpha * inv; }                    // :543
