@@ -331,10 +331,10 @@ __global__ void k_collapse4(int nwork, const Work4* __restrict__ work_in, Work4*
     }
     BvhNode4 nd;
     for (int k = 0; k < 4; k++) {
-        nd.lox[k] = nd.loy[k] = nd.loz[k] = INFINITY;          // empty slot: a point at +inf never passes the slab test
-        nd.hix[k] = nd.hiy[k] = nd.hiz[k] = INFINITY;
-        nd.child[k] = leaf_code(0, 1);
-        nd.pad[k] = 0;
+        BvhChild& C = nd.c[k];
+        C.lox = C.loy = C.loz = C.hix = C.hiy = C.hiz = INFINITY;   // empty slot: a point at +inf never passes the slab test
+        C.code = leaf_code(0, 1);
+        C.pad = 0;
     }
     for (int k = 0; k < nch; k++) {
         const int x = ch[k];
@@ -352,9 +352,10 @@ __global__ void k_collapse4(int nwork, const Work4* __restrict__ work_in, Work4*
                 code = (int)slot;
             }
         }
-        nd.lox[k] = b.lo[0]; nd.loy[k] = b.lo[1]; nd.loz[k] = b.lo[2];
-        nd.hix[k] = b.hi[0]; nd.hiy[k] = b.hi[1]; nd.hiz[k] = b.hi[2];
-        nd.child[k] = code;
+        BvhChild& C = nd.c[k];
+        C.lox = b.lo[0]; C.loy = b.lo[1]; C.loz = b.lo[2];
+        C.hix = b.hi[0]; C.hiy = b.hi[1]; C.hiz = b.hi[2];
+        C.code = code;
     }
     nodes[me.out] = nd;
     atomicMax(&stats[0], me.depth + 1u);
@@ -369,14 +370,14 @@ __global__ void k_emit_tiny(int n, const Box* __restrict__ boxes, BvhNode4* __re
         for (int k = 0; k < 3; k++) { u.lo[k] = fminf(u.lo[k], boxes[i].lo[k]); u.hi[k] = fmaxf(u.hi[k], boxes[i].hi[k]); }
     BvhNode4 nd;
     for (int k = 0; k < 4; k++) {
-        nd.lox[k] = nd.loy[k] = nd.loz[k] = INFINITY;
-        nd.hix[k] = nd.hiy[k] = nd.hiz[k] = INFINITY;
-        nd.child[k] = leaf_code(0, 1);
-        nd.pad[k] = 0;
+        BvhChild& C = nd.c[k];
+        C.lox = C.loy = C.loz = C.hix = C.hiy = C.hiz = INFINITY;
+        C.code = leaf_code(0, 1);
+        C.pad = 0;
     }
-    nd.lox[0] = u.lo[0]; nd.loy[0] = u.lo[1]; nd.loz[0] = u.lo[2];
-    nd.hix[0] = u.hi[0]; nd.hiy[0] = u.hi[1]; nd.hiz[0] = u.hi[2];
-    nd.child[0] = leaf_code(0, n);
+    nd.c[0].lox = u.lo[0]; nd.c[0].loy = u.lo[1]; nd.c[0].loz = u.lo[2];
+    nd.c[0].hix = u.hi[0]; nd.c[0].hiy = u.hi[1]; nd.c[0].hiz = u.hi[2];
+    nd.c[0].code = leaf_code(0, n);
     nodes[0] = nd;
     stats[0] = 1; stats[1] = 1;
     for (int i = 0; i < n; i++) leaf_pos[i] = (uint32_t)i;

@@ -53,7 +53,9 @@ struct fovpt_ctx {
     std::vector<void*> tex_pixels;
     uint32_t num_tris = 0, any_catcher = 0;
     // probe
-    DevBuf pr_data, pr_pdfx, pr_cdfx, pr_pdfy, pr_cdfy;
+    DevBuf pr_data, pr_pdfx, pr_cdfx, pr_pdfy, pr_cdfy, pr_guidex, pr_guidey;
+    bool guide_ok = false;
+    int guide_w = 0, guide_h = 0;
     // frame buffers (resize)
     DevBuf fb_frame, fb_accum, fb_color, fb_normal, fb_albedo;
     // wavefront state
@@ -164,8 +166,6 @@ int ensure_state(fovpt_ctx* c, size_t slots, size_t launches)
         HIPCHK(c, c->counters.reserve(sizeof(Counters)));
         HIPCHK(c, hipMemsetAsync(c->counters.p, 0, sizeof(Counters), c->stream));
     }
-    HIPCHK(c, c->spill.reserve((size_t)c->grid * FOVPT_BLOCK * FOVPT_STACK_SPILL * sizeof(int)));
-    HIPCHK(c, c->spill_shadow.reserve((size_t)c->grid_shadow * FOVPT_BLOCK * FOVPT_STACK_SPILL * sizeof(int)));
     return FOVPT_OK;
 }
 
@@ -200,6 +200,11 @@ int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passe
     float* dst[4] = {fd.eye, fd.U, fd.V, fd.W};
     for (int k = 0; k < 4; k++) { dst[k][0] = cam[k]->x; dst[k][1] = cam[k]->y; dst[k][2] = cam[k]->z; }
     fd.probe = lp->probe;
+    // the guide tables belong to the probe this context uploaded; a caller-supplied foreign probe is searched plainly
+    const bool own_probe = c->guide_ok && lp->probe.cdfValuesX == (float*)c->pr_cdfx.p && lp->probe.cdfValuesY == (float*)c->pr_cdfy.p
+                           && lp->probe.width == c->guide_w && lp->probe.height == c->guide_h;
+    fd.guide_x = own_probe ? (const uint32_t*)c->pr_guidex.p : nullptr;
+    fd.guide_y = own_probe ? (const uint32_t*)c->pr_guidey.p : nullptr;
     fd.accum = lp->frame.accum_buffer;
     fd.frame = lp->frame.frame_buffer;
     fd.total_slots = (uint32_t)slots;
@@ -243,15 +248,15 @@ int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passe
     // Shadow chain (stream `ss`):  occlusion(it) as soon as shade(it) has queued its rays.
     // Every radiance cell has one writer, so the only joins are: shade(it+2) reuses the shadow queue
     // buffer of bounce it, and resolve needs everything.
-    { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qa, sq[0], cap, cnt, 0, -1, (int*)c->spill.p, grid); }
+    { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qa, sq[0], cap, cnt, 0, -1, grid); }
     for (int it = 0; it < iters; it++) {
         if (it >= 2) HIPCHK(c, hipStreamWaitEvent(st, c->ev_shadow[it - 2], 0));
         { Timed t(c, 2); fovpt_launch_shade(st, fd, sc, ps, qa, qb, sq[it & 1], cap, cnt, it, grid); }
         HIPCHK(c, hipEventRecord(c->ev_shade[it], st));
         HIPCHK(c, hipStreamWaitEvent(ss, c->ev_shade[it], 0));
-        { Timed t(c, 3, ss); fovpt_launch_traverse(ss, sc, ps, qb, sq[it & 1], cap, cnt, -1, it, (int*)c->spill_shadow.p, c->grid_shadow); }
+        { Timed t(c, 3, ss); fovpt_launch_traverse(ss, sc, ps, qb, sq[it & 1], cap, cnt, -1, it, c->grid_shadow); }
         HIPCHK(c, hipEventRecord(c->ev_shadow[it], ss));
-        if (it + 1 < iters) { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qb, sq[0], cap, cnt, it + 1, -1, (int*)c->spill.p, grid); }
+        if (it + 1 < iters) { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qb, sq[0], cap, cnt, it + 1, -1, grid); }
         uint32_t* tmp = qa; qa = qb; qb = tmp;
     }
     for (int it = iters >= 2 ? iters - 2 : 0; it < iters; it++) HIPCHK(c, hipStreamWaitEvent(st, c->ev_shadow[it], 0));
@@ -297,8 +302,11 @@ int fovpt_create(fovpt_ctx** out, int device)
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
     c->grid = c->num_cus * 8;                 // 8 blocks of 256 = 32 waves per CU, grid-stride over the queues
     c->grid_shadow = c->num_cus * 4;
-    e = hipStreamCreate(&c->stream);
-    if (e == hipSuccess) e = hipStreamCreate(&c->shadow_stream);
+    // the main chain is the critical path: give it the higher priority so occlusion waves only fill gaps
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    e = hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_hi);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->shadow_stream, hipStreamDefault, prio_lo);
     for (int k = 0; k <= FOVPT_MAX_ITERS && e == hipSuccess; k++) {
         e = hipEventCreateWithFlags(&c->ev_shade[k], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_shadow[k], hipEventDisableTiming);
@@ -421,9 +429,9 @@ int fovpt_set_scene(fovpt_ctx* c, const fovpt_mesh_desc* meshes, int num_meshes,
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     (void)hipFree(d_flat); (void)hipFree(d_mesh_of);
     if (be != hipSuccess) return fail(c, FOVPT_E_DEVICE, "LBVH build: %s", errbuf);
-    if (3 * br.max_depth + 1 > FOVPT_STACK_LDS + FOVPT_STACK_SPILL) {       // a wide node leaves at most 3 entries behind
+    if (3 * br.max_depth + 1 > FOVPT_STACK) {       // a wide node leaves at most 3 entries behind
         (void)hipFree(br.nodes); (void)hipFree(br.tris);
-        return fail(c, FOVPT_E_BVH_DEPTH, "hierarchy depth %u needs more than the %d traversal stack entries", br.max_depth, FOVPT_STACK_LDS + FOVPT_STACK_SPILL);
+        return fail(c, FOVPT_E_BVH_DEPTH, "hierarchy depth %u needs more than the %d traversal stack entries", br.max_depth, FOVPT_STACK);
     }
     c->nodes = br.nodes; c->tris = br.tris;
     c->num_tris = (uint32_t)ntri;
@@ -455,6 +463,22 @@ int fovpt_set_probe(fovpt_ctx* c, int width, int height, const fovpt_float4* dat
     HIPCHK(c, hipMemcpy(c->pr_pdfy.p, pdfY, (size_t)height * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->pr_cdfy.p, cdfY, (size_t)height * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->pr_data.p, data, n * 16, hipMemcpyHostToDevice));
+    // guide tables for the two CDF searches of ProbeSample: only valid on non-decreasing CDFs
+    bool sorted = true;
+    for (int row = 0; row < height && sorted; row++) {
+        const float* cr = cdfX + (size_t)row * width;
+        for (int k = 1; k < width; k++) if (!(cr[k] >= cr[k - 1])) { sorted = false; break; }
+    }
+    for (int k = 1; k < height && sorted; k++) if (!(cdfY[k] >= cdfY[k - 1])) sorted = false;
+    c->guide_ok = false;
+    if (sorted) {
+        HIPCHK(c, c->pr_guidex.reserve((size_t)height * (width + 2) * 4));
+        HIPCHK(c, c->pr_guidey.reserve((size_t)(height + 2) * 4));
+        fovpt_launch_build_guide(c->stream, (const float*)c->pr_cdfx.p, width, height, (uint32_t*)c->pr_guidex.p);
+        fovpt_launch_build_guide(c->stream, (const float*)c->pr_cdfy.p, height, 1, (uint32_t*)c->pr_guidey.p);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->guide_ok = true; c->guide_w = width; c->guide_h = height;
+    }
     memset(out, 0, sizeof(*out));
     out->width = width; out->height = height;
     out->data = (fovpt_float4*)c->pr_data.p;

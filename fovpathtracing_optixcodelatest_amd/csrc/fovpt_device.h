@@ -12,8 +12,8 @@
 #ifndef FOVPT_LEAF_MAX
 #define FOVPT_LEAF_MAX 4          // triangles per BVH leaf (<= 8: three bits in the leaf code)
 #endif
-#define FOVPT_STACK_LDS 16        // traversal stack entries kept in LDS per lane (a wide node pushes up to 3)
-#define FOVPT_STACK_SPILL 48      // deeper entries go to a per-lane slice in HBM
+#define FOVPT_STACK 64            // traversal stack entries per ray, all in LDS (a wide node leaves <= 3 behind)
+#define FOVPT_QUADS_PER_BLOCK (FOVPT_BLOCK / 4)
 #define FOVPT_MAX_PASSES 3
 #define FOVPT_MAX_ITERS 63         // wavefront iterations per frame (max_depth + catcher pass-throughs)
 #define FOVPT_SHARDS 8            // queue shards: one append counter per blockIdx % 8 (~ per XCD)
@@ -30,15 +30,19 @@ struct alignas(16) TriRec {
 };                                // 48 B
 static_assert(sizeof(TriRec) == 48, "TriRec");
 
-// 4-wide BVH node, SoA over the children so one lane tests the four boxes with straight-line code
-// (eight 16-byte loads per visit).  child >= 0: index of a wide node; child < 0: leaf,
-// ~child = (first_tri << 3) | (count-1).  An unused slot holds the degenerate box lo = hi = +inf,
+// 4-wide BVH node: four 32-byte child records.  The traversal gives one ray to four adjacent lanes
+// (a quad); lane j of the quad owns child j and fetches exactly its record (two 16-byte loads, the
+// quad's eight loads cover the 128-byte node).  code >= 0: index of a wide node; code < 0: leaf,
+// ~code = (first_tri << 3) | (count-1).  An unused slot holds the degenerate box lo = hi = +inf,
 // which no ray passes.
+struct alignas(16) BvhChild {
+    float lox, loy, loz, hix;
+    float hiy, hiz;
+    int32_t code;
+    uint32_t pad;
+};
 struct alignas(16) BvhNode4 {
-    float lox[4], loy[4], loz[4];
-    float hix[4], hiy[4], hiz[4];
-    int32_t child[4];
-    uint32_t pad[4];
+    BvhChild c[4];
 };                                // 128 B
 static_assert(sizeof(BvhNode4) == 128, "BvhNode4");
 
@@ -63,6 +67,7 @@ struct SceneView {
     uint32_t any_catcher;
 };
 
+
 struct PassDev {                  // one optixLaunch worth of parameters
     uint32_t gw, gh;              // launch grid
     uint32_t fx, fy, fz;          // frame.factor
@@ -84,6 +89,8 @@ struct FrameDev {
     uint32_t cx, cy;              // frame.c
     float eye[3], U[3], V[3], W[3];
     fovpt_probe probe;            // device pointers
+    const uint32_t* guide_x;      // lower_bound guide tables for probe.cdfValuesX / Y, or null
+    const uint32_t* guide_y;
     fovpt_float4* accum;
     uint32_t* frame;
     uint32_t total_slots;
@@ -141,8 +148,9 @@ void fovpt_launch_generate(hipStream_t st, const FrameDev& fd, PathState ps, uin
 // One launch that traces the shadow queue of iteration it_shadow (if >= 0) and the radiance queue of
 // iteration it_closest (if >= 0).
 void fovpt_launch_traverse(hipStream_t st, SceneView sc, PathState ps, const uint32_t* queue, ShadowQueue sq, uint32_t cap,
-                           Counters* cnt, int it_closest, int it_shadow, int* spill, int grid);
+                           Counters* cnt, int it_closest, int it_shadow, int grid);
 void fovpt_launch_shade(hipStream_t st, const FrameDev& fd, SceneView sc, PathState ps, const uint32_t* queue_in, uint32_t* queue_out,
                         ShadowQueue sq, uint32_t cap, Counters* cnt, int depth, int grid);
 void fovpt_launch_resolve(hipStream_t st, const FrameDev& fd, PathState ps);
+void fovpt_launch_build_guide(hipStream_t st, const float* cdf, int n, int segments, uint32_t* guide);
 void fovpt_launch_math(hipStream_t st, int op, const float* a, const float* b, float* out, size_t n);

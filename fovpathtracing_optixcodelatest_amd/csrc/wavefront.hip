@@ -130,12 +130,38 @@ __device__ inline int lower_bound(const float* __restrict__ a, int lower, int up
     }
     return lower;
 }
-__device__ inline void probe_sample(const fovpt_probe& pr, V3& dir, V3& color, float& pdf, Rng& rng)   // :138-169
+// lower_bound through a guide table: G[m] = lower_bound(a, value = m/K) for m = 0..K+1 (relative to the
+// start of the segment).  For a value r in bucket k = int(r*K) the answer lies in [G[k-1], G[k+2]], so
+// the binary search starts on a range of a few elements instead of the whole row: ~3 dependent
+// loads instead of log2(n).  On a sorted array lower_bound is unique, so the result is the one the
+// reference's full search returns (Probe.cuh:119-136); fovpt_set_probe only enables the tables
+// after checking that the CDFs are non-decreasing.
+__device__ inline int lower_bound_guided(const float* __restrict__ a, const uint32_t* __restrict__ guide, int base, int n, float value)
+{
+    int k = (int)(value * (float)n);
+    k = max(0, min(k, n - 1));
+    int lower = base + (int)guide[max(k - 1, 0)];
+    int upper = base + (int)guide[min(k + 2, n + 1)];
+    while (lower < upper) {
+        int mid = lower + (upper - lower) / 2;
+        if (a[mid] < value) lower = mid + 1;
+        else upper = mid;
+    }
+    return lower;
+}
+__device__ inline void probe_sample(const fovpt_probe& pr, const uint32_t* __restrict__ guide_x, const uint32_t* __restrict__ guide_y,
+                                    V3& dir, V3& color, float& pdf, Rng& rng)   // :138-169
 {
     float r1 = rng.randf01();
     float r2 = rng.randf01();
-    int row = lower_bound(pr.cdfValuesY, 0, pr.height, r1);
-    int col = lower_bound(pr.cdfValuesX, row * pr.width, (row + 1) * pr.width, r2) - row * pr.width;
+    int row, col;
+    if (guide_x) {
+        row = lower_bound_guided(pr.cdfValuesY, guide_y, 0, pr.height, r1);
+        col = lower_bound_guided(pr.cdfValuesX, guide_x + (size_t)row * (pr.width + 2), row * pr.width, pr.width, r2) - row * pr.width;
+    } else {
+        row = lower_bound(pr.cdfValuesY, 0, pr.height, r1);
+        col = lower_bound(pr.cdfValuesX, row * pr.width, (row + 1) * pr.width, r2) - row * pr.width;
+    }
     color = v3(((const float4*)pr.data)[row * pr.width + col]);
     pdf = pr.pdfValuesX[row * pr.width + col] * pr.pdfValuesY[row];
     float u = col / float(pr.width);
@@ -368,6 +394,34 @@ __device__ inline uint32_t block_append(uint32_t* shard_counters, uint32_t cap, 
     return pos;
 }
 
+// Two appends at once (shadow queue and next radiance queue) behind ONE pair of barriers.
+__device__ inline void block_append2(uint32_t* counters_a, bool pred_a, uint32_t* counters_b, bool pred_b, uint32_t cap,
+                                     uint32_t* s_scratch /* [10] */, uint32_t& pos_a, uint32_t& pos_b)
+{
+    const unsigned long long ma = __ballot(pred_a), mb = __ballot(pred_b);
+    const uint32_t lane = __lane_id();
+    const uint32_t wave = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const uint32_t pa = __popcll(ma & below), pb = __popcll(mb & below);
+    if (lane == 0) { s_scratch[wave] = (uint32_t)__popcll(ma); s_scratch[4 + wave] = (uint32_t)__popcll(mb); }
+    __syncthreads();
+    const uint32_t a0 = s_scratch[0], a1 = s_scratch[1], a2 = s_scratch[2], a3 = s_scratch[3];
+    const uint32_t b0 = s_scratch[4], b1 = s_scratch[5], b2 = s_scratch[6], b3 = s_scratch[7];
+    const uint32_t shard = blockIdx.x & (FOVPT_SHARDS - 1);
+    if (threadIdx.x == 0) {
+        const uint32_t ta = a0 + a1 + a2 + a3;
+        s_scratch[8] = ta ? atomicAdd(&counters_a[shard], ta) : 0u;
+    }
+    if (threadIdx.x == 64) {
+        const uint32_t tb = b0 + b1 + b2 + b3;
+        s_scratch[9] = tb ? atomicAdd(&counters_b[shard], tb) : 0u;
+    }
+    __syncthreads();
+    pos_a = shard * cap + s_scratch[8] + (wave > 0 ? a0 : 0u) + (wave > 1 ? a1 : 0u) + (wave > 2 ? a2 : 0u) + pa;
+    pos_b = shard * cap + s_scratch[9] + (wave > 0 ? b0 : 0u) + (wave > 1 ? b1 : 0u) + (wave > 2 ? b2 : 0u) + pb;
+    __syncthreads();                 // s_scratch is reused by the next iteration
+}
+
 // logical index -> physical index of a sharded queue (all in scalar registers, no indexing)
 struct ShardMap {
     uint32_t p1, p2, p3, p4, p5, p6, p7, p8;     // exclusive prefix sums of the 8 shard counts (p0 = 0)
@@ -460,26 +514,34 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, Pat
 }
 
 // ---- traversal ---------------------------------------------------------------------------
-struct Stack {
-    int* lds;          // this lane's column: lds[k * FOVPT_BLOCK]
-    int* spill;        // this lane's slice in HBM: spill[k * stride]
-    uint32_t stride;
-    int sp;
-    __device__ inline void push(int v)
-    {
-        if (sp < FOVPT_STACK_LDS) lds[sp * FOVPT_BLOCK] = v;
-        else spill[(size_t)(sp - FOVPT_STACK_LDS) * stride] = v;
-        sp++;
-    }
-    __device__ inline int pop()
-    {
-        sp--;
-        // the LDS read is unconditional (ds_read, no flat load); the spill slice is the rare path
-        int v = lds[(sp < FOVPT_STACK_LDS ? sp : FOVPT_STACK_LDS - 1) * FOVPT_BLOCK];
-        if (sp >= FOVPT_STACK_LDS) v = spill[(size_t)(sp - FOVPT_STACK_LDS) * stride];
-        return v;
-    }
-};
+// Quad-cooperative traversal: FOUR adjacent lanes share one ray.  On a wide node lane j tests child j
+// (so a node visit is one box test deep instead of four), on a leaf lane j tests triangle j; the four
+// results meet through DPP quad permutes (register-to-register, no LDS).  A wave thus carries 16
+// rays, each step is ~3x shorter than with one lane per ray, and divergence is between 16 rays
+// instead of 64.  With the single-thread latency of a CU (~1 us per dependent traversal step at
+// one lane per ray) this is what bounds a frame: every bounce ends with the longest ray of its launch.
+template <int K>
+__device__ inline float quad_bcast(float v)        // value of lane K of this lane's quad
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K * 0x55, 0xf, 0xf, false));
+}
+template <int K>
+__device__ inline int quad_bcast(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, K * 0x55, 0xf, 0xf, false);
+}
+__device__ inline float quad_min(float v)
+{
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)));   // [1,0,3,2]
+    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)));   // [2,3,0,1]
+    return v;
+}
+__device__ inline int quad_or(int v)
+{
+    v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+    return v;
+}
 
 struct RayT {
     float ox, oy, oz, dx, dy, dz;
@@ -543,146 +605,129 @@ __device__ inline TriRec load_tri(const TriRec* __restrict__ tris, uint32_t i)
 #define TMIN 0.01f     // deviceProgram.cu:41
 #define TMAX 1e16f     // deviceProgram.cu:42
 
-// sort two (distance, child) pairs so that the first is not farther than the second
-__device__ inline void cswap(float& ta, int& ca, float& tb, int& cb)
-{
-    const bool sw = tb < ta;
-    const float t = sw ? tb : ta, u = sw ? ta : tb;
-    const int c = sw ? cb : ca, d = sw ? ca : cb;
-    ta = t; tb = u; ca = c; cb = d;
-}
+#define TRAV_DONE ((int)0x80000000)     // cur: traversal finished (never a valid leaf code: first_tri < 2^28)
 
-// While-while traversal of the 4-wide BVH.  Closest-hit rays visit children front to back (sorting
-// network on the four entry distances) and shrink the interval to the best hit; any-hit rays take the
-// children in storage order and leave at the first front-facing candidate.
+// One ray per quad.  Everything that steers control flow (cur, sp, the quad-wide best distance) is
+// identical in the four lanes; each lane keeps the best hit among the triangles IT tested and the
+// four are merged once, at the end, by (t, primitive id) -- the same total order as a sequential scan.
 template <bool ANY_HIT>
-__device__ inline void traverse(const SceneView& sc, const RayT& r, Stack& st, float& best_t, float& best_u, float& best_v,
-                                uint32_t& best_pos, uint32_t& best_prim, bool& occluded)
+__device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __restrict__ stack /* [e * QUADS_PER_BLOCK] */, uint32_t j,
+                                     float& bt, float& bu, float& bv, uint32_t& bpos, uint32_t& bprim, bool& occluded)
 {
-    st.sp = 0;
-    int cur = 0;                       // root
-#if FOVPT_V_STEPSTAT
-    uint32_t steps = 0;
-#define STEP_RETURN do { best_u = __uint_as_float(steps); return; } while (0)
-#else
-#define STEP_RETURN return
-#endif
+    int cur = 0, sp = 0;
+    float btq = INFINITY;              // min over the quad of bt: prunes boxes
     for (;;) {
-        // ---- wide internal nodes
+        // ---- wide internal nodes: lane j owns child j
         while (cur >= 0) {
-#if FOVPT_V_STEPSTAT
-            steps++;
-#endif
-            const float4* np = (const float4*)(sc.nodes + cur);
-            const float4 lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5];
-            const int4 ch = ((const int4*)np)[6];
-            const float lim = ANY_HIT ? TMAX : fminf(TMAX, best_t * 1.000001f);
-            float t0, t1, t2, t3;
-            const bool h0 = box_hit(r, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, TMIN, lim, t0);
-            const bool h1 = box_hit(r, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, TMIN, lim, t1);
-            const bool h2 = box_hit(r, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, TMIN, lim, t2);
-            const bool h3 = box_hit(r, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, TMIN, lim, t3);
-            if (!(h0 || h1 || h2 || h3)) {
-                if (st.sp == 0) STEP_RETURN;
-                cur = st.pop();
+            const float4* np = (const float4*)(sc.nodes + cur) + 2 * j;
+            const float4 a = np[0], b = np[1];
+            const int code = __float_as_int(b.z);
+            const float lim = ANY_HIT ? TMAX : fminf(TMAX, btq * 1.000001f);
+            float t;
+            const bool h = box_hit(r, a.x, a.y, a.z, a.w, b.x, b.y, TMIN, lim, t);
+            const float tk = h ? t : INFINITY;
+            const float t0 = quad_bcast<0>(tk), t1 = quad_bcast<1>(tk), t2 = quad_bcast<2>(tk), t3 = quad_bcast<3>(tk);
+            const int c0 = quad_bcast<0>(code), c1 = quad_bcast<1>(code), c2 = quad_bcast<2>(code), c3 = quad_bcast<3>(code);
+            const bool h0 = t0 < INFINITY, h1 = t1 < INFINITY, h2 = t2 < INFINITY, h3 = t3 < INFINITY;
+            const int H = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+            if (H == 0) {
+                if (sp == 0) { cur = TRAV_DONE; break; }
+                cur = stack[--sp * FOVPT_QUADS_PER_BLOCK];
                 continue;
             }
+            int rank, next;
             if (ANY_HIT) {
-                // continue with the first hit child, stack the others (sorting them by distance was
-                // measured slower: an occluder anywhere ends the ray)
-                int next = 0;
-                bool have = false;
-                if (h0) { next = ch.x; have = true; }
-                if (h1) { if (have) st.push(ch.y); else { next = ch.y; have = true; } }
-                if (h2) { if (have) st.push(ch.z); else { next = ch.z; have = true; } }
-                if (h3) { if (have) st.push(ch.w); else { next = ch.w; have = true; } }
-                cur = next;
+                // any order will do: storage order (sorting by distance was measured slower)
+                rank = (j > 0 && h0) + (j > 1 && h1) + (j > 2 && h2);
+                next = h0 ? c0 : (h1 ? c1 : (h2 ? c2 : c3));
             } else {
-                float a = h0 ? t0 : INFINITY, b = h1 ? t1 : INFINITY, c = h2 ? t2 : INFINITY, d = h3 ? t3 : INFINITY;
-                int ca = ch.x, cb = ch.y, cc = ch.z, cd = ch.w;
-                cswap(a, ca, b, cb); cswap(c, cc, d, cd);
-                cswap(a, ca, c, cc); cswap(b, cb, d, cd);
-                cswap(b, cb, c, cc);
-                // a <= b <= c <= d; misses carry +inf and sort to the end.  Farthest first onto the stack.
-                if (d < INFINITY) st.push(cd);
-                if (c < INFINITY) st.push(cc);
-                if (b < INFINITY) st.push(cb);
-                cur = ca;
+                // front to back: rank by (entry distance, child index)
+                rank = (int)(t0 < tk || (t0 == tk && j > 0)) + (int)(t1 < tk || (t1 == tk && j > 1))
+                     + (int)(t2 < tk || (t2 == tk && j > 2)) + (int)(t3 < tk);
+                // (for j == k the term is false by construction: t_k < t_k is false and j > k is false)
+                float tm = t0; next = c0;
+                if (t1 < tm) { tm = t1; next = c1; }
+                if (t2 < tm) { tm = t2; next = c2; }
+                if (t3 < tm) { tm = t3; next = c3; }
             }
+            // the H-1 other hits go onto the stack in one step, farthest deepest
+            if (h && rank >= 1) stack[(sp + H - 1 - rank) * FOVPT_QUADS_PER_BLOCK] = code;
+            sp += H - 1;
+            cur = next;
         }
-        // ---- leaf
+        if (cur == TRAV_DONE) return;
+        // ---- leaf: lane j owns triangle j
         {
-            const uint32_t code = (uint32_t)~cur;
-            const uint32_t first = code >> 3, count = (code & 7u) + 1u;
-            for (uint32_t k = 0; k < count; k++) {
+            const uint32_t lcode = (uint32_t)~cur;
+            const uint32_t first = lcode >> 3, count = (lcode & 7u) + 1u;
+            int occ = 0;
+            for (uint32_t k = j; k < count; k += 4) {
                 const TriRec T = load_tri(sc.tris, first + k);
                 float t, u, v, det;
                 if (!tri_hit(r, T, t, u, v, det)) continue;
                 if (!(t > TMIN && t < TMAX)) continue;
                 if (ANY_HIT) {
-                    if (det > 0.0f) { occluded = true; STEP_RETURN; }      // front face: counter-clockwise seen from the origin
-                } else if (t < best_t || (t == best_t && T.prim < best_prim)) {
-                    best_t = t; best_u = u; best_v = v; best_pos = first + k; best_prim = T.prim;
+                    if (det > 0.0f) occ = 1;                          // front face: counter-clockwise seen from the origin
+                } else if (t < bt || (t == bt && T.prim < bprim)) {
+                    bt = t; bu = u; bv = v; bpos = first + k; bprim = T.prim;
                 }
             }
-            if (st.sp == 0) STEP_RETURN;
-            cur = st.pop();
-#if FOVPT_V_STEPSTAT
-            steps += 0x10000u;
-#endif
+            if (ANY_HIT) {
+                if (quad_or(occ)) { occluded = true; return; }
+            } else {
+                btq = quad_min(bt);
+            }
+            if (sp == 0) return;
+            cur = stack[--sp * FOVPT_QUADS_PER_BLOCK];
         }
     }
 }
 
-// One traversal launch per bounce: the occlusion rays of iteration it_shadow and the closest-hit rays of
-// iteration it_closest form one index space [shadow | radiance], walked with a static grid-stride
-// loop (waves are homogeneous except the one at the seam).  The few, slow any-hit rays of one bounce
-// thus run beside the many closest-hit rays of the next instead of leaving the chip 60 % empty.
-// (Dynamic work fetching was measured and rejected: with <= 2 rays per resident lane per launch a
-// returning atomic per wave costs more than the imbalance it removes -- DESIGN.md section 4.)
+// One traversal launch handles the occlusion rays of iteration it_shadow and/or the closest-hit rays of
+// iteration it_closest as one index space [shadow | radiance], one ray per QUAD of lanes, static
+// grid-stride over quads (waves are homogeneous in ray kind: the shadow part is padded to 16 rays).
+// (Dynamic work fetching with per-lane replacement was measured and rejected: with so few rays per
+// resident lane per launch a returning atomic per wave costs more than the imbalance it removes.)
 __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneView sc, PathState ps, const uint32_t* __restrict__ queue, ShadowQueue sq,
-                                                          uint32_t cap, Counters* __restrict__ cnt, int it_closest, int it_shadow,
-                                                          int* __restrict__ spill)
+                                                                         uint32_t cap, Counters* __restrict__ cnt, int it_closest, int it_shadow)
 {
-    __shared__ int s_stack[FOVPT_STACK_LDS * FOVPT_BLOCK];
+    __shared__ int s_stack[FOVPT_STACK * FOVPT_QUADS_PER_BLOCK];
     ShardMap ms, mq;
     ms.load(cnt->sq[it_shadow >= 0 ? it_shadow : 0]);
     mq.load(cnt->q[it_closest >= 0 ? it_closest : 0]);
     const uint32_t n_sh = it_shadow >= 0 ? ms.total() : 0u;
     const uint32_t n_cl = it_closest >= 0 ? mq.total() : 0u;
-    const uint32_t n_sh_pad = (n_sh + 63u) & ~63u;                 // keep waves homogeneous
+    const uint32_t n_sh_pad = (n_sh + 15u) & ~15u;                 // 16 rays per wave
     const uint32_t n_total = n_sh_pad + n_cl;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (n_cl) atomicAdd(&cnt->stat_radiance, (unsigned long long)n_cl);
         if (n_sh) atomicAdd(&cnt->stat_shadow, (unsigned long long)n_sh);
         if (it_closest == 0) atomicAdd(&cnt->stat_paths, (unsigned long long)n_cl);
     }
-    Stack st;
-    st.lds = s_stack + threadIdx.x;
-    st.stride = gridDim.x * FOVPT_BLOCK;
-    st.spill = spill + blockIdx.x * FOVPT_BLOCK + threadIdx.x;
-    for (uint32_t i = blockIdx.x * FOVPT_BLOCK + threadIdx.x; i < n_total; i += gridDim.x * FOVPT_BLOCK) {
+    const uint32_t j = threadIdx.x & 3u;
+    int* stack = s_stack + (threadIdx.x >> 2);
+    const uint32_t quads = gridDim.x * FOVPT_QUADS_PER_BLOCK;
+    for (uint32_t i = blockIdx.x * FOVPT_QUADS_PER_BLOCK + (threadIdx.x >> 2); i < n_total; i += quads) {
         if (i < n_sh_pad) {
             if (i >= n_sh) continue;
             const uint32_t ph = ms.phys(i, cap);
             const float4 o = sq.o[ph], d = sq.d[ph];
             RayT r;
             ray_setup(r, o, d);
-            float bt = INFINITY, bu, bv;
-            uint32_t bpos, bprim = 0;
+            float bt = INFINITY, bu = 0.f, bv = 0.f;
+            uint32_t bpos = 0, bprim = 0;
             bool occ = false;
-            traverse<true>(sc, r, st, bt, bu, bv, bpos, bprim, occ);
-            // the deferred NEE add of SampleLights / SampleShadow (deviceProgram.cu:323-341,367-385)
-#if FOVPT_V_STEPSTAT
-            sq.val_occ[ph].w = bu; sq.val_vis[ph].w = occ ? 1.f : 0.f;
-#endif
-            const float4 val = occ ? sq.val_occ[ph] : sq.val_vis[ph];
-            // every (slot, depth) cell has exactly one writer, so this is a plain store and the shadow
-            // rays of a bounce may run at any time before resolve (own stream, see fovpt_api.hip)
-            const uint32_t slot = __float_as_uint(o.w);
-            const uint32_t target = __float_as_uint(d.w);
-            float4* cell = target == 0xffffffffu ? ps.alpha + slot : ps.rad + ((size_t)target * ps.stride + slot);
-            *cell = make_float4(val.x, val.y, val.z, 0.f);
+            traverse_quad<true>(sc, r, stack, j, bt, bu, bv, bpos, bprim, occ);
+            if (j == 0) {
+                // the deferred NEE add of SampleLights / SampleShadow (deviceProgram.cu:323-341,367-385).
+                // Every (slot, depth) cell has exactly one writer, so this is a plain store and the shadow
+                // rays of a bounce may run at any time before resolve (own stream, see fovpt_api.hip)
+                const float4 val = occ ? sq.val_occ[ph] : sq.val_vis[ph];
+                const uint32_t slot = __float_as_uint(o.w);
+                const uint32_t target = __float_as_uint(d.w);
+                float4* cell = target == 0xffffffffu ? ps.alpha + slot : ps.rad + ((size_t)target * ps.stride + slot);
+                *cell = make_float4(val.x, val.y, val.z, 0.f);
+            }
         } else {
             const uint32_t slot = queue[mq.phys(i - n_sh_pad, cap)];
             RayT r;
@@ -690,8 +735,15 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
             float bt = INFINITY, bu = 0.f, bv = 0.f;
             uint32_t bpos = 0xffffffffu, bprim = 0xffffffffu;
             bool occ = false;
-            traverse<false>(sc, r, st, bt, bu, bv, bpos, bprim, occ);
-            ps.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(bpos));
+            traverse_quad<false>(sc, r, stack, j, bt, bu, bv, bpos, bprim, occ);
+            // merge the four lanes' candidates: lowest t, then lowest primitive id, then lowest lane
+            const float t0 = quad_bcast<0>(bt), t1 = quad_bcast<1>(bt), t2 = quad_bcast<2>(bt), t3 = quad_bcast<3>(bt);
+            const int p0 = quad_bcast<0>((int)bprim), p1 = quad_bcast<1>((int)bprim), p2 = quad_bcast<2>((int)bprim), p3 = quad_bcast<3>((int)bprim);
+            uint32_t w = 0; float tw = t0; uint32_t pw = (uint32_t)p0;
+            if (t1 < tw || (t1 == tw && (uint32_t)p1 < pw)) { w = 1; tw = t1; pw = (uint32_t)p1; }
+            if (t2 < tw || (t2 == tw && (uint32_t)p2 < pw)) { w = 2; tw = t2; pw = (uint32_t)p2; }
+            if (t3 < tw || (t3 == tw && (uint32_t)p3 < pw)) { w = 3; tw = t3; pw = (uint32_t)p3; }
+            if (j == w) ps.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(bpos));
         }
     }
 }
@@ -728,7 +780,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_shade(const FrameDev fd, SceneV
                                                        const uint32_t* __restrict__ queue_in, uint32_t* __restrict__ queue_out,
                                                        ShadowQueue sq, uint32_t cap, Counters* __restrict__ cnt, int depth_iter)
 {
-    __shared__ uint32_t s_scratch[6];
+    __shared__ uint32_t s_scratch[10];
     ShardMap mq;
     mq.load(cnt->q[depth_iter]);
     const uint32_t n = mq.total();
@@ -791,7 +843,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_shade(const FrameDev fd, SceneV
                         outEta = 1.0f;
                     // ---- SampleLights / SampleShadow :303-387 with the occlusion test deferred
                     V3 wi, skyColor; float skyPdf;
-                    probe_sample(fd.probe, wi, skyColor, skyPdf, rng);
+                    probe_sample(fd.probe, fd.guide_x, fd.guide_y, wi, skyColor, skyPdf, rng);
                     V3 sum_hit = v3(0.0f);        // value of `sum` on the branch that evaluates the BSDF
                     {
                         const float bsdfPdf = bsdf_pdf(mat, rayEta, outEta, N, wo, wi);
@@ -873,9 +925,9 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_shade(const FrameDev fd, SceneV
             ps.rng[slot] = rs;
         }
         // ---- wavefront-ballot compaction into the next queues
-        const uint32_t spos = block_append(cnt->sq[depth_iter], cap, want_shadow, s_scratch);
+        uint32_t spos, qpos;
+        block_append2(cnt->sq[depth_iter], want_shadow, cnt->q[depth_iter + 1], want_next, cap, s_scratch, spos, qpos);
         if (want_shadow) { sq.o[spos] = sh_o; sq.d[spos] = sh_d; sq.val_vis[spos] = sh_vis; sq.val_occ[spos] = sh_occ; }
-        const uint32_t qpos = block_append(cnt->q[depth_iter + 1], cap, want_next, s_scratch);
         if (want_next) queue_out[qpos] = slot;
     }
 }
@@ -977,6 +1029,18 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_resolve(const FrameDev fd, Path
     }
 }
 
+// ---- probe guide tables (built once per setProbe) ------------------------------------------
+// guide[seg * (n+2) + m] = lower_bound(cdf[seg*n .. seg*n+n), m / n) - seg*n, m = 0..n+1
+__global__ void k_build_guide(const float* __restrict__ cdf, int n, int segments, uint32_t* __restrict__ guide)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)segments * (n + 2);
+    if (i >= total) return;
+    const int seg = (int)(i / (n + 2)), m = (int)(i - (size_t)seg * (n + 2));
+    const float value = (float)m / (float)n;
+    guide[i] = (uint32_t)(lower_bound(cdf, seg * n, (seg + 1) * n, value) - seg * n);
+}
+
 // ---- device self-test --------------------------------------------------------------------
 __global__ void k_math(int op, const float* a, const float* b, float* out, size_t n)
 {
@@ -1005,9 +1069,9 @@ void fovpt_launch_generate(hipStream_t st, const FrameDev& fd, PathState ps, uin
     hipLaunchKernelGGL(k_generate, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, ps, queue0, cap, cnt, total_slots);
 }
 void fovpt_launch_traverse(hipStream_t st, SceneView sc, PathState ps, const uint32_t* queue, ShadowQueue sq, uint32_t cap,
-                           Counters* cnt, int it_closest, int it_shadow, int* spill, int grid)
+                           Counters* cnt, int it_closest, int it_shadow, int grid)
 {
-    hipLaunchKernelGGL(k_traverse, dim3(grid), dim3(FOVPT_BLOCK), 0, st, sc, ps, queue, sq, cap, cnt, it_closest, it_shadow, spill);
+    hipLaunchKernelGGL(k_traverse, dim3(grid), dim3(FOVPT_BLOCK), 0, st, sc, ps, queue, sq, cap, cnt, it_closest, it_shadow);
 }
 void fovpt_launch_shade(hipStream_t st, const FrameDev& fd, SceneView sc, PathState ps, const uint32_t* queue_in, uint32_t* queue_out,
                         ShadowQueue sq, uint32_t cap, Counters* cnt, int depth, int grid)
@@ -1018,6 +1082,11 @@ void fovpt_launch_resolve(hipStream_t st, const FrameDev& fd, PathState ps)
 {
     dim3 grid((fd.w + 63) / 64, (fd.h + 3) / 4);
     hipLaunchKernelGGL(k_resolve, grid, dim3(FOVPT_BLOCK), 0, st, fd, ps);
+}
+void fovpt_launch_build_guide(hipStream_t st, const float* cdf, int n, int segments, uint32_t* guide)
+{
+    const size_t total = (size_t)segments * (n + 2);
+    hipLaunchKernelGGL(k_build_guide, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cdf, n, segments, guide);
 }
 void fovpt_launch_math(hipStream_t st, int op, const float* a, const float* b, float* out, size_t n)
 {
