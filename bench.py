@@ -165,10 +165,12 @@ def main():
     ps = r.stats()
     cfg.profile = 0
     r.config = cfg
-    # k_traverse is the one traversal kernel: each launch walks the shadow rays of one bounce and
-    # the radiance rays of the next (fovpt_stats books all of its launches under ms_trace)
+    # k_traverse is the one traversal kernel (4 lanes per ray): closest-hit launches run on the main
+    # stream (fovpt_stats books them under ms_trace), occlusion launches on the shadow stream
+    # (ms_shadow); rocprofv3 reports both under the one kernel name
     dom = "k_traverse"
-    ms_k, n_launch = ps.ms_trace, ps.n_trace_launches
+    ms_k = ps.ms_trace + ps.ms_shadow
+    n_launch = ps.n_trace_launches + ps.n_shadow_launches
     n_rays = ps.radiance_rays + ps.shadow_rays
     b_closest = algorithmic_bytes_per_ray(int(ps.num_triangles), "closest")
     b_any = algorithmic_bytes_per_ray(int(ps.num_triangles), "any")
@@ -189,7 +191,8 @@ def main():
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
         "avg_launch_ms": round(avg_ms, 5), "launches_per_frame": n_launch / prof_frames,
         "rays_per_launch": n_rays / max(1, n_launch), "algorithmic_bytes_per_ray": round(b_ray, 1),
-        "per_frame_ms": {"generate": ps.ms_generate / prof_frames, "trace": ps.ms_trace / prof_frames,
+        "per_frame_ms": {"generate": ps.ms_generate / prof_frames, "traverse_closest": ps.ms_trace / prof_frames,
+                         "traverse_occlusion_async": ps.ms_shadow / prof_frames,
                          "shade": ps.ms_shade / prof_frames, "resolve": ps.ms_resolve / prof_frames},
     }
 

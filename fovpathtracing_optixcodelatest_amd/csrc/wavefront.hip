@@ -776,7 +776,10 @@ __device__ inline float4 tex2d(const TexDev& T, float u, float v)
 
 #define FLAG_ALPHA_ONE 4u      // prd.alpha = make_float3(1) happened (deviceProgram.cu:689)
 
-__global__ __launch_bounds__(FOVPT_BLOCK) void k_shade(const FrameDev fd, SceneView sc, PathState ps,
+#ifndef FOVPT_V_SHADEWAVES
+#define FOVPT_V_SHADEWAVES 1
+#endif
+__global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const FrameDev fd, SceneView sc, PathState ps,
                                                        const uint32_t* __restrict__ queue_in, uint32_t* __restrict__ queue_out,
                                                        ShadowQueue sq, uint32_t cap, Counters* __restrict__ cnt, int depth_iter)
 {
@@ -958,15 +961,24 @@ __device__ inline uint32_t make_color(const V3& c)                              
 // candidate launch-index range along one axis for pixel coordinate x (resolve)
 __device__ inline void writer_range(uint32_t x, uint32_t frame_dim, uint32_t factor, int fill, uint32_t off, uint32_t grid, long long& lo, long long& hi)
 {
+    // r = x - (int32)off, a = max(0, ceil((r - (fill-1)) / f)), b = floor(r / f) (or grid-1 on the clamped edge).
+    // 64-bit integer division is a long software routine on the GPU: everything that fits goes through
+    // 32-bit unsigned division (always, for sane offsets).
     const long long r = (long long)x - (long long)(int32_t)off;
-    const long long f = factor ? factor : 1;
-    const long long s1 = fill - 1;
-    auto floordiv = [](long long a, long long b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
-    long long a = floordiv(r - s1 + f - 1, f);      // ceil((r - s1) / f)
-    if (a < 0) a = 0;
+    const uint32_t f = factor ? factor : 1u;
+    const long long num = r - (long long)(fill - 1);          // a = ceil(num / f)
+    long long a;
+    if (num <= 0) a = 0;
+    else if (num < 0x7fffffffll) a = (long long)(((uint32_t)num + f - 1u) / f);
+    else a = (num + f - 1) / (long long)f;
     long long b;
     if (x + 1 == frame_dim) b = (long long)grid - 1;  // clamp at :554 folds everything beyond the edge onto it
-    else { b = r < 0 ? -1 : r / f; if (b > (long long)grid - 1) b = (long long)grid - 1; }
+    else {
+        if (r < 0) b = -1;
+        else if (r < 0x7fffffffll) b = (long long)((uint32_t)r / f);
+        else b = r / (long long)f;
+        if (b > (long long)grid - 1) b = (long long)grid - 1;
+    }
     lo = a; hi = b;
 }
 

@@ -35,8 +35,8 @@ for profile in (0, 1):
     print("profile", profile, "ms/frame %.3f" % (dt * 1e3), "rays/frame %.0f" % rays, "Mray/s %.1f" % (rays / dt / 1e6),
           "paths", s.paths // frames, "rad", s.radiance_rays // frames, "shadow", s.shadow_rays // frames)
     if profile:
-        print("  per-frame ms: gen %.3f traverse %.3f shade %.3f resolve %.3f" % tuple(
-            x / frames for x in (s.ms_generate, s.ms_trace, s.ms_shade, s.ms_resolve)))
+        print("  per-frame ms: gen %.3f closest %.3f occlusion(async) %.3f shade %.3f resolve %.3f" % tuple(
+            x / frames for x in (s.ms_generate, s.ms_trace, s.ms_shadow, s.ms_shade, s.ms_resolve)))
 print("bvh nodes", s.num_bvh_nodes, "depth", s.bvh_max_depth, "build ms %.2f" % s.ms_bvh_build, "bvh MB %.1f" % (s.bvh_bytes / 1e6), "tri MB %.1f" % (s.tri_bytes / 1e6))
 acc = r.downloadAccum()
 print("accum mean", acc[..., :3].mean(axis=(0, 1)), "max", acc[..., :3].max(), "finite", np.isfinite(acc).all())
