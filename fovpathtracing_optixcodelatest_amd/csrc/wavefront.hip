@@ -23,6 +23,9 @@
 #include "fovpt_device.h"
 #include "../../include/fovpt_detmath.h"
 
+#ifndef FOVPT_V_WAVEAPPEND
+#define FOVPT_V_WAVEAPPEND 0
+#endif
 #ifndef FOVPT_V_STEPSTAT
 #define FOVPT_V_STEPSTAT 0
 #endif
@@ -929,7 +932,24 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
         }
         // ---- wavefront-ballot compaction into the next queues
         uint32_t spos, qpos;
+#if FOVPT_V_WAVEAPPEND
+        {   // per-wave append (no barrier): one atomic per wave and queue on the wave's shard
+            const uint32_t lane = __lane_id();
+            const uint32_t shard = ((blockIdx.x << 2) + (threadIdx.x >> 6)) & (FOVPT_SHARDS - 1);
+            const unsigned long long ma = __ballot(want_shadow), mb = __ballot(want_next);
+            const unsigned long long below = (1ull << lane) - 1ull;
+            uint32_t ba = 0, bb = 0;
+            if (lane == 0) {
+                if (ma) ba = atomicAdd(&cnt->sq[depth_iter][shard], (uint32_t)__popcll(ma));
+                if (mb) bb = atomicAdd(&cnt->q[depth_iter + 1][shard], (uint32_t)__popcll(mb));
+            }
+            ba = __shfl(ba, 0); bb = __shfl(bb, 0);
+            spos = shard * cap + ba + (uint32_t)__popcll(ma & below);
+            qpos = shard * cap + bb + (uint32_t)__popcll(mb & below);
+        }
+#else
         block_append2(cnt->sq[depth_iter], want_shadow, cnt->q[depth_iter + 1], want_next, cap, s_scratch, spos, qpos);
+#endif
         if (want_shadow) { sq.o[spos] = sh_o; sq.d[spos] = sh_d; sq.val_vis[spos] = sh_vis; sq.val_occ[spos] = sh_occ; }
         if (want_next) queue_out[qpos] = slot;
     }
@@ -982,62 +1002,123 @@ __device__ inline void writer_range(uint32_t x, uint32_t frame_dim, uint32_t fac
     lo = a; hi = b;
 }
 
+// Resolve as a tiled LDS reduction.  A block owns a 64 x 4 pixel tile.
+//   A. every pixel thread finds its last writer in the reference's launch order (gather)
+//   B. runs of pixels with the same writer elect a leader; leaders are ballot-compacted into a tile-local
+//      work list in LDS (a 4x4 periphery block is 16 pixels but ONE colour)
+//   C. the first n threads of the block each reduce one list entry: ordered sum over the launch index's
+//      sample slots and bounce cells, alpha, backplate mix, exposure, Reinhard, sRGB -> LDS
+//   D. every pixel thread fetches its colour from LDS and writes float4 accum + rgba8, coalesced
 __global__ __launch_bounds__(FOVPT_BLOCK) void k_resolve(const FrameDev fd, PathState ps)
 {
-    const uint32_t x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const uint32_t y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (x >= (uint32_t)fd.w || y >= (uint32_t)fd.h) return;
+    __shared__ uint32_t s_key[FOVPT_BLOCK];        // launch record id of the pixel's writer
+    __shared__ uint32_t s_idx[FOVPT_BLOCK];        // leader thread -> tile list position
+    __shared__ uint32_t s_list_li[FOVPT_BLOCK];    // tile list: launch index ...
+    __shared__ uint32_t s_list_p[FOVPT_BLOCK];     // ... and pass
+    __shared__ float4 s_accum[FOVPT_BLOCK];        // result per list entry: accum_color (pre-blend)
+    __shared__ uint32_t s_rgba[FOVPT_BLOCK];       // result per list entry: tone-mapped pixel
+    __shared__ uint32_t s_wave[4];
+
+    const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const uint32_t x = blockIdx.x * 64 + tx;
+    const uint32_t y = blockIdx.y * 4 + ty;
+    const bool inside = x < (uint32_t)fd.w && y < (uint32_t)fd.h;
     const uint32_t image_index = y * (uint32_t)fd.w + x;
-    for (int p = fd.npass - 1; p >= 0; p--) {
-        const PassDev& P = fd.pass[p];
-        if (P.fill <= 0) continue;
-        long long xa, xb, ya, yb;
-        writer_range(x, (uint32_t)fd.w, P.fx, P.fill, P.offx, P.gw, xa, xb);
-        writer_range(y, (uint32_t)fd.h, P.fy, P.fill, P.offy, P.gh, ya, yb);
-        for (long long ly = yb; ly >= ya; ly--) {
-            for (long long lx = xb; lx >= xa; lx--) {
-                uint32_t ix, iy;
-                if (!ring_alive(fd, P, (uint32_t)lx, (uint32_t)ly, ix, iy)) continue;
-                // last writer found
-                if (!launch_owned(fd, p, (uint32_t)lx, (uint32_t)ly)) {
-                    fd.accum[image_index] = fovpt_float4{0.f, 0.f, 0.f, 0.f};    // another rank's pixel: keep the sum-gather exact
-                    fd.frame[image_index] = 0u;
-                    return;
+
+    // ---- A: last writer of this pixel
+    int state = 0;                 // 0 nobody, 1 a launch index this rank owns, 2 another rank's
+    int wp = 0;
+    uint32_t wli = 0, key = 0xffffffffu;
+    if (inside) {
+        for (int p = fd.npass - 1; p >= 0 && state == 0; p--) {
+            const PassDev& P = fd.pass[p];
+            if (P.fill <= 0) continue;
+            long long xa, xb, ya, yb;
+            writer_range(x, (uint32_t)fd.w, P.fx, P.fill, P.offx, P.gw, xa, xb);
+            writer_range(y, (uint32_t)fd.h, P.fy, P.fill, P.offy, P.gh, ya, yb);
+            for (long long ly = yb; ly >= ya && state == 0; ly--) {
+                for (long long lx = xb; lx >= xa; lx--) {
+                    uint32_t ix, iy;
+                    if (!ring_alive(fd, P, (uint32_t)lx, (uint32_t)ly, ix, iy)) continue;
+                    state = launch_owned(fd, p, (uint32_t)lx, (uint32_t)ly) ? 1 : 2;
+                    wp = p;
+                    wli = (uint32_t)ly * P.gw + (uint32_t)lx;
+                    key = P.launch_base + wli;
+                    break;
                 }
-                const uint32_t li = (uint32_t)ly * P.gw + (uint32_t)lx;
-                const uint32_t s0 = P.slot_base + li * P.spp;
-                V3 result = v3(0.0f), alpha = v3(0.0f);
-                for (uint32_t s = 0; s < P.spp; s++) {                                     // :536-537, in sample order
-                    const uint32_t slot = s0 + s;
-                    const V3 direct = v3(0.0f) + v3(ps.rad[slot]);                            // :523
-                    V3 indirect = v3(0.0f);
-                    for (int dd = 1; dd < fd.max_depth; dd++)                                  // :526, in bounce order
-                        indirect = indirect + v3(ps.rad[(size_t)dd * ps.stride + slot]);
-                    result = result + (direct + indirect);
-                    const bool one = (ps.rng[slot].z & FLAG_ALPHA_ONE) != 0u;
-                    alpha = alpha + (one ? v3(1.0f) : v3(ps.alpha[slot]));
-                }
-                const float sppf = (float)P.spp;
-                { const float inv = 1.0f / sppf; alpha = alpha * inv; }                    // :543
-                const V3 backplate = v3(ps.backplate[P.launch_base + li]);
-                const V3 color = (backplate * sppf) * sub_sv(1.0f, alpha) + result;        // :558
-                V3 accum_color = div_vs(color, sppf);                                      // :560
-                if (fd.accumulate && P.subframe > 0 && !P.redraw) {
-                    // PT_sv4_vmv2/deviceProgram.cu:545-553
-                    accum_color = clamp3(accum_color, 0.0f, 10.0f);
-                    const float alpha_value = 1.0f / (float)(P.subframe + 1);
-                    const fovpt_float4 pv = fd.accum[image_index];
-                    accum_color = lerp3(v3(pv.x, pv.y, pv.z), accum_color, alpha_value);
-                }
-                fd.accum[image_index] = fovpt_float4{accum_color.x, accum_color.y, accum_color.z, 1.0f};   // :582
-                const V3 exposed = accum_color * 16.0f;                                    // :586
-                fd.frame[image_index] = make_color(reinhard(exposed, 1.0f));               // :597
-                return;
             }
         }
     }
-    if (fd.world > 1) {   // nobody writes this pixel: contribute zero to the gather, rank 0 keeps the old value
-        if (fd.rank != 0) { fd.accum[image_index] = fovpt_float4{0.f, 0.f, 0.f, 0.f}; fd.frame[image_index] = 0u; }
+    if (state != 1) key = 0xffffffffu;
+    s_key[threadIdx.x] = key;
+    __syncthreads();
+
+    // ---- B: run leaders -> tile list
+    const bool leader = state == 1 && (tx == 0 || s_key[threadIdx.x - 1] != key);
+    const unsigned long long lm = __ballot(leader);
+    if (tx == 0) s_wave[ty] = (uint32_t)__popcll(lm);
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < ty; w++) base += s_wave[w];
+    const uint32_t nlist = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    if (leader) {
+        const uint32_t pos = base + (uint32_t)__popcll(lm & ((1ull << tx) - 1ull));
+        s_idx[threadIdx.x] = pos;
+        s_list_li[pos] = wli;
+        s_list_p[pos] = (uint32_t)wp;
+    }
+    __syncthreads();
+
+    // ---- C: one thread per distinct writer in the tile
+    if (threadIdx.x < nlist) {
+        const PassDev& P = fd.pass[s_list_p[threadIdx.x]];
+        const uint32_t li = s_list_li[threadIdx.x];
+        const uint32_t s0 = P.slot_base + li * P.spp;
+        V3 result = v3(0.0f), alpha = v3(0.0f);
+        for (uint32_t s = 0; s < P.spp; s++) {                                     // :536-537, in sample order
+            const uint32_t slot = s0 + s;
+            const V3 direct = v3(0.0f) + v3(ps.rad[slot]);                            // :523
+            V3 indirect = v3(0.0f);
+            for (int dd = 1; dd < fd.max_depth; dd++)                                  // :526, in bounce order
+                indirect = indirect + v3(ps.rad[(size_t)dd * ps.stride + slot]);
+            result = result + (direct + indirect);
+            const bool one = (ps.rng[slot].z & FLAG_ALPHA_ONE) != 0u;
+            alpha = alpha + (one ? v3(1.0f) : v3(ps.alpha[slot]));
+        }
+        const float sppf = (float)P.spp;
+        { const float inv = 1.0f / sppf; alpha = alpha * inv; }                    // :543
+        const V3 backplate = v3(ps.backplate[P.launch_base + li]);
+        const V3 color = (backplate * sppf) * sub_sv(1.0f, alpha) + result;        // :558
+        const V3 accum_color = div_vs(color, sppf);                                // :560
+        s_accum[threadIdx.x] = f4(accum_color, 1.0f);
+        s_rgba[threadIdx.x] = make_color(reinhard(accum_color * 16.0f, 1.0f));     // :586,597
+    }
+    __syncthreads();
+
+    // ---- D: write the tile
+    if (!inside) return;
+    if (state == 1) {
+        uint32_t t = threadIdx.x;
+        while (!(t == ty * 64 || s_key[t - 1] != key)) t--;                        // start of this pixel's run
+        const uint32_t e = s_idx[t];
+        const PassDev& P = fd.pass[wp];
+        float4 a = s_accum[e];
+        uint32_t rgba = s_rgba[e];
+        if (fd.accumulate && P.subframe > 0 && !P.redraw) {
+            // PT_sv4_vmv2/deviceProgram.cu:545-553: clamp + running mean against THIS pixel's history
+            V3 accum_color = clamp3(v3(a), 0.0f, 10.0f);
+            const float alpha_value = 1.0f / (float)(P.subframe + 1);
+            const fovpt_float4 pv = fd.accum[image_index];
+            accum_color = lerp3(v3(pv.x, pv.y, pv.z), accum_color, alpha_value);
+            a = f4(accum_color, 1.0f);
+            rgba = make_color(reinhard(accum_color * 16.0f, 1.0f));
+        }
+        fd.accum[image_index] = fovpt_float4{a.x, a.y, a.z, 1.0f};                 // :582
+        fd.frame[image_index] = rgba;
+    } else if (state == 2 || (fd.world > 1 && fd.rank != 0)) {
+        // another rank's pixel (or nobody's, on a rank other than 0): zero keeps the sum-gather exact
+        fd.accum[image_index] = fovpt_float4{0.f, 0.f, 0.f, 0.f};
+        fd.frame[image_index] = 0u;
     }
 }
 
