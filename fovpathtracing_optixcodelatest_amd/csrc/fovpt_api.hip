@@ -220,7 +220,7 @@ int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passe
 
     PathState ps;
     ps.ray_o = (float4*)c->s_ray_o.p; ps.ray_d = (float4*)c->s_ray_d.p; ps.thr = (float4*)c->s_thr.p;
-    ps.rng = (uint4*)c->s_rng.p; ps.hit = (float4*)c->s_hit.p; ps.rad = (float4*)c->s_rad.p; ps.stride = (size_t)slots;
+    ps.rng = (uint4*)c->s_rng.p; ps.hit = (float4*)c->s_hit.p; ps.rad = (float4*)c->s_rad.p; ps.stride = (size_t)c->cfg.max_depth;
     ps.alpha = (float4*)c->s_alpha.p; ps.backplate = (float4*)c->s_backplate.p;
     ShadowQueue sq[2];
     for (int k = 0; k < 2; k++) {

@@ -106,9 +106,9 @@ struct PathState {
     float4* thr;        // pathThroughput.xyz, rayEta
     uint4* rng;         // Random.seed1, Random.seed2, stateFlags (DONE 1, SECONDARY 2, ALPHA_ONE 4) | depth << 8, unused
     float4* hit;        // t, u, v, tri position in leaf order as bits (0xffffffff = miss)
-    float4* rad;        // [depth][slot]: prd.radiance of the segment at that depth (directLight = term 0,
+    float4* rad;        // [slot][depth]: prd.radiance of the segment at that depth (directLight = term 0,
                         // indirectLight = terms 1.. summed in order); one writer per cell
-    size_t stride;      // slots per depth plane of rad
+    size_t stride;      // cells per slot (= max_depth)
     float4* alpha;      // prd.alpha contribution of a shadow-catcher primary hit
     float4* backplate;  // per launch record: backplate of the last sample (deviceProgram.cu:495)
 };
@@ -116,7 +116,7 @@ struct PathState {
 // Shadow (occlusion) ray queue, indexed by queue position.
 struct ShadowQueue {
     float4* o;          // origin.xyz, slot as bits
-    float4* d;          // direction.xyz, target as bits (depth plane of rad, or 0xffffffff = alpha)
+    float4* d;          // direction.xyz, target as bits (depth cell of rad, or 0xffffffff = alpha)
     float4* val_vis;    // value added when NOT occluded
     float4* val_occ;    // value added when occluded
 };

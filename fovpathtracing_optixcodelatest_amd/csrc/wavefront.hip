@@ -503,7 +503,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, Pat
             ps.thr[slot] = make_float4(1.f, 1.f, 1.f, 1.0f);                    // pathThroughput, rayEta
             ps.rng[slot] = make_uint4(rng.s1, rng.s2, 0u, 0u);                  // stateFlags 0, depth 0
             for (int dd = 0; dd < fd.max_depth; dd++)                          // directLight / indirectLight terms, :450-451
-                ps.rad[(size_t)dd * ps.stride + slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+                ps.rad[(size_t)slot * ps.stride + dd] = make_float4(0.f, 0.f, 0.f, 0.f);
             ps.alpha[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (s == P.spp - 1) {                                               // backplate of the last sample, :495
                 float u, v;
@@ -728,7 +728,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
                 const float4 val = occ ? sq.val_occ[ph] : sq.val_vis[ph];
                 const uint32_t slot = __float_as_uint(o.w);
                 const uint32_t target = __float_as_uint(d.w);
-                float4* cell = target == 0xffffffffu ? ps.alpha + slot : ps.rad + ((size_t)target * ps.stride + slot);
+                float4* cell = target == 0xffffffffu ? ps.alpha + slot : ps.rad + ((size_t)slot * ps.stride + target);
                 *cell = make_float4(val.x, val.y, val.z, 0.f);
             }
         } else {
@@ -901,7 +901,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
                     } else {
                         // the segment counts: prd.radiance becomes the depth-th term of directLight (depth 0) /
                         // indirectLight (:522-527).  One cell per (slot, depth), summed in order by resolve.
-                        float4* cell = ps.rad + ((size_t)depth * ps.stride + slot);
+                        float4* cell = ps.rad + ((size_t)slot * ps.stride + depth);
                         if (!catcher && !same) {
                             want_shadow = true;
                             sh_o = f4(P, __uint_as_float(slot)); sh_d = f4(wi, __uint_as_float((uint32_t)depth));
@@ -982,20 +982,22 @@ __device__ inline uint32_t make_color(const V3& c)                              
 __device__ inline void writer_range(uint32_t x, uint32_t frame_dim, uint32_t factor, int fill, uint32_t off, uint32_t grid, long long& lo, long long& hi)
 {
     // r = x - (int32)off, a = max(0, ceil((r - (fill-1)) / f)), b = floor(r / f) (or grid-1 on the clamped edge).
-    // 64-bit integer division is a long software routine on the GPU: everything that fits goes through
-    // 32-bit unsigned division (always, for sane offsets).
+    // Integer division is a long software routine on the GPU: power-of-two factors (1, 2, 4 in every
+    // pass the reference launches) shift, everything else that fits uses 32-bit division.
     const long long r = (long long)x - (long long)(int32_t)off;
     const uint32_t f = factor ? factor : 1u;
+    const bool pow2 = (f & (f - 1u)) == 0u;
+    const int sh = 31 - __clz((int)f);
     const long long num = r - (long long)(fill - 1);          // a = ceil(num / f)
     long long a;
     if (num <= 0) a = 0;
-    else if (num < 0x7fffffffll) a = (long long)(((uint32_t)num + f - 1u) / f);
+    else if (num < 0x7fffffffll) a = pow2 ? (long long)(((uint32_t)num + f - 1u) >> sh) : (long long)(((uint32_t)num + f - 1u) / f);
     else a = (num + f - 1) / (long long)f;
     long long b;
     if (x + 1 == frame_dim) b = (long long)grid - 1;  // clamp at :554 folds everything beyond the edge onto it
     else {
         if (r < 0) b = -1;
-        else if (r < 0x7fffffffll) b = (long long)((uint32_t)r / f);
+        else if (r < 0x7fffffffll) b = pow2 ? (long long)((uint32_t)r >> sh) : (long long)((uint32_t)r / f);
         else b = r / (long long)f;
         if (b > (long long)grid - 1) b = (long long)grid - 1;
     }
@@ -1030,7 +1032,9 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_resolve(const FrameDev fd, Path
     int wp = 0;
     uint32_t wli = 0, key = 0xffffffffu;
     if (inside) {
-        for (int p = fd.npass - 1; p >= 0 && state == 0; p--) {
+#pragma unroll
+        for (int p = FOVPT_MAX_PASSES - 1; p >= 0; p--) {          // static indices: the pass records stay in SGPRs
+            if (p >= fd.npass || state != 0) continue;
             const PassDev& P = fd.pass[p];
             if (P.fill <= 0) continue;
             long long xa, xb, ya, yb;
@@ -1077,10 +1081,11 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_resolve(const FrameDev fd, Path
         V3 result = v3(0.0f), alpha = v3(0.0f);
         for (uint32_t s = 0; s < P.spp; s++) {                                     // :536-537, in sample order
             const uint32_t slot = s0 + s;
-            const V3 direct = v3(0.0f) + v3(ps.rad[slot]);                            // :523
+            const float4* cells = ps.rad + (size_t)slot * ps.stride;                 // one 16*D-byte record per slot
+            const V3 direct = v3(0.0f) + v3(cells[0]);                                // :523
             V3 indirect = v3(0.0f);
             for (int dd = 1; dd < fd.max_depth; dd++)                                  // :526, in bounce order
-                indirect = indirect + v3(ps.rad[(size_t)dd * ps.stride + slot]);
+                indirect = indirect + v3(cells[dd]);
             result = result + (direct + indirect);
             const bool one = (ps.rng[slot].z & FLAG_ALPHA_ONE) != 0u;
             alpha = alpha + (one ? v3(1.0f) : v3(ps.alpha[slot]));
