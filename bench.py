@@ -105,22 +105,34 @@ def main():
     r.config = cfg
     r.launchParams.frame.c.x, r.launchParams.frame.c.y = W // 2, H // 2
 
-    # the frame the ranks render into and gather: a torch tensor, handed to the library as the
-    # caller-owned render target (render(CUDAOutputBuffer&), SimplePathtracer.cpp:216-226)
-    frame = torch.zeros(H * W, dtype=torch.int32, device="cuda")
-    target = renderer.OutputBuffer(frame.data_ptr())
-    r.launchParams.frame.frame_buffer = target.map()
+    # the frame the ranks render into and gather: torch tensors, handed to the library as the
+    # caller-owned render target (render(CUDAOutputBuffer&), SimplePathtracer.cpp:216-226).  Two of
+    # them at N > 1: the RCCL reduce-gather of frame k runs beside the rendering of frame k+1.
+    frames = [torch.zeros(H * W, dtype=torch.int32, device="cuda") for _ in range(2 if world > 1 else 1)]
+    pending = [None, None]
+    step_no = [0]
 
     def step():
+        k = step_no[0] % len(frames)
+        step_no[0] += 1
+        if pending[k] is not None:                             # the gather that last used this buffer
+            pending[k].wait()                                  # orders torch's stream after the RCCL op ...
+            torch.cuda.current_stream().synchronize()          # ... and the host (the library has its own stream)
+            pending[k] = None
         # the shipped app resets subframe_index to 0 before every render() (main.cpp:402-407)
         r.launchParams.frame.subframe_index = 0
+        r.launchParams.frame.frame_buffer = frames[k].data_ptr()
         r.render_async()
         if world > 1:
-            r.synchronize()                                    # library stream -> torch stream hand-off
-            multigpu.gather_frame(frame, dst=0)
+            r.synchronize()                                    # library stream -> RCCL stream hand-off
+            pending[k] = multigpu.gather_frame(frames[k], dst=0, async_op=True)
 
     def fence():
         r.synchronize()
+        for k in range(len(pending)):
+            if pending[k] is not None:
+                pending[k].wait()
+                pending[k] = None
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -242,7 +254,7 @@ def main():
         }
         # the timed frames are parity frames too: the oracle just rendered the same frame
         import numpy as np
-        gpu_px = frame.cpu().numpy().view(np.uint32).reshape(H, W)
+        gpu_px = frames[(step_no[0] - 1) % len(frames)].cpu().numpy().view(np.uint32).reshape(H, W)
         out["parity_vs_oracle_rgba8_mismatch"] = int((gpu_px != F.frame).sum())
 
     if rank == 0:

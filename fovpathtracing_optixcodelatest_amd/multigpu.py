@@ -18,9 +18,11 @@ def launch_owner(pass_index, lx, ly, world, tile_w=8, tile_h=4):
     return ((lx // tile_w) + 3 * (ly // tile_h) + pass_index) % world
 
 
-def gather_frame(frame: torch.Tensor, dst: int = 0, group=None):
-    """Sum-reduce the per-rank frames (int32 rgba8 words, or float accum) onto rank `dst`."""
+def gather_frame(frame: torch.Tensor, dst: int = 0, group=None, async_op: bool = False):
+    """Sum-reduce the per-rank frames (int32 rgba8 words, or float accum) onto rank `dst`.
+    With async_op=True returns the work handle (None when there is nothing to do) so the caller can
+    overlap the gather of frame k with the rendering of frame k+1."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return frame
-    dist.reduce(frame, dst=dst, op=dist.ReduceOp.SUM, group=group)
-    return frame
+        return None if async_op else frame
+    work = dist.reduce(frame, dst=dst, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+    return work if async_op else frame
