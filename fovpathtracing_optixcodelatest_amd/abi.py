@@ -136,7 +136,7 @@ class Config(C.Structure):
         ("spp_periphery", C.c_int32), ("spp_middle", C.c_int32), ("spp_fovea", C.c_int32),
         ("spp_uniform", C.c_int32), ("max_depth", C.c_int32), ("accumulate", C.c_int32),
         ("rank", C.c_int32), ("world", C.c_int32), ("tile_w", C.c_int32), ("tile_h", C.c_int32),
-        ("profile", C.c_int32), ("sort_rays", C.c_int32), ("reserved", C.c_int32 * 1),
+        ("profile", C.c_int32), ("write_guides", C.c_int32), ("reserved", C.c_int32 * 1),
     ]
 
     @classmethod

@@ -59,7 +59,7 @@ struct fovpt_ctx {
     // frame buffers (resize)
     DevBuf fb_frame, fb_accum, fb_color, fb_normal, fb_albedo;
     // wavefront state
-    DevBuf s_ray_o, s_ray_d, s_thr, s_rng, s_hit, s_rad, s_alpha, s_backplate;
+    DevBuf s_ray_o, s_ray_d, s_thr, s_rng, s_hit, s_rad, s_alpha, s_backplate, s_guide_n, s_guide_a;
     DevBuf q_a, q_b, sq_o[2], sq_d[2], sq_vis[2], sq_occ[2], counters, spill, spill_shadow;
     int grid = 2048, grid_shadow = 1024;
     // stats
@@ -153,6 +153,7 @@ int ensure_state(fovpt_ctx* c, size_t slots, size_t launches)
     HIPCHK(c, c->s_hit.reserve(slots * v)); HIPCHK(c, c->s_alpha.reserve(slots * v));
     HIPCHK(c, c->s_rad.reserve(slots * v * (size_t)c->cfg.max_depth));
     HIPCHK(c, c->s_backplate.reserve(launches * v));
+    if (c->cfg.write_guides) { HIPCHK(c, c->s_guide_n.reserve(slots * v)); HIPCHK(c, c->s_guide_a.reserve(slots * v)); }
     // sharded queues: FOVPT_SHARDS regions of `slots` entries each (memory is laid out for 288 GB);
     // the shadow queue is double-buffered because bounce it's occlusion rays may still be in flight
     // on the shadow stream while bounce it+1 is being shaded
@@ -207,6 +208,10 @@ int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passe
     fd.guide_y = own_probe ? (const uint32_t*)c->pr_guidey.p : nullptr;
     fd.accum = lp->frame.accum_buffer;
     fd.frame = lp->frame.frame_buffer;
+    if (c->cfg.write_guides) {
+        if (c->any_catcher) return fail(c, FOVPT_E_INVALID, "write_guides is not available with shadow-catcher materials");
+        fd.g_normal = lp->frame.normal_buffer; fd.g_color = lp->frame.color_buffer; fd.g_albedo = lp->frame.albedo_buffer;
+    }
     fd.total_slots = (uint32_t)slots;
     fd.max_depth = c->cfg.max_depth;
     fd.accumulate = c->cfg.accumulate;
@@ -222,6 +227,8 @@ int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passe
     ps.ray_o = (float4*)c->s_ray_o.p; ps.ray_d = (float4*)c->s_ray_d.p; ps.thr = (float4*)c->s_thr.p;
     ps.rng = (uint4*)c->s_rng.p; ps.hit = (float4*)c->s_hit.p; ps.rad = (float4*)c->s_rad.p; ps.stride = (size_t)c->cfg.max_depth;
     ps.alpha = (float4*)c->s_alpha.p; ps.backplate = (float4*)c->s_backplate.p;
+    ps.guide_n = c->cfg.write_guides ? (float4*)c->s_guide_n.p : nullptr;
+    ps.guide_a = c->cfg.write_guides ? (float4*)c->s_guide_a.p : nullptr;
     ShadowQueue sq[2];
     for (int k = 0; k < 2; k++) {
         sq[k].o = (float4*)c->sq_o[k].p; sq[k].d = (float4*)c->sq_d[k].p;
@@ -331,7 +338,7 @@ void fovpt_destroy(fovpt_ctx* c)
     free_scene(c);
     DevBuf* bufs[] = {&c->tri_tc, &c->meshes, &c->textures, &c->pr_data, &c->pr_pdfx, &c->pr_cdfx, &c->pr_pdfy, &c->pr_cdfy,
                       &c->fb_frame, &c->fb_accum, &c->fb_color, &c->fb_normal, &c->fb_albedo,
-                      &c->s_ray_o, &c->s_ray_d, &c->s_thr, &c->s_rng, &c->s_hit, &c->s_rad, &c->s_alpha, &c->s_backplate,
+                      &c->s_ray_o, &c->s_ray_d, &c->s_thr, &c->s_rng, &c->s_hit, &c->s_rad, &c->s_alpha, &c->s_backplate, &c->s_guide_n, &c->s_guide_a,
                       &c->q_a, &c->q_b, &c->sq_o[0], &c->sq_d[0], &c->sq_vis[0], &c->sq_occ[0],
                       &c->sq_o[1], &c->sq_d[1], &c->sq_vis[1], &c->sq_occ[1], &c->counters, &c->spill, &c->spill_shadow};
     for (DevBuf* b : bufs) b->release();
@@ -501,6 +508,9 @@ int fovpt_resize(fovpt_ctx* c, int width, int height, fovpt_frame_ptrs* out)
     HIPCHK(c, c->fb_color.reserve(n * 16)); HIPCHK(c, c->fb_normal.reserve(n * 16)); HIPCHK(c, c->fb_albedo.reserve(n * 16));
     HIPCHK(c, hipMemset(c->fb_frame.p, 0, n * 4));
     HIPCHK(c, hipMemset(c->fb_accum.p, 0, n * 16));
+    HIPCHK(c, hipMemset(c->fb_color.p, 0, n * 16));
+    HIPCHK(c, hipMemset(c->fb_normal.p, 0, n * 16));
+    HIPCHK(c, hipMemset(c->fb_albedo.p, 0, n * 16));
     out->frame_buffer = (uint32_t*)c->fb_frame.p; out->accum_buffer = (fovpt_float4*)c->fb_accum.p;
     out->color_buffer = (fovpt_float4*)c->fb_color.p; out->normal_buffer = (fovpt_float4*)c->fb_normal.p;
     out->albedo_buffer = (fovpt_float4*)c->fb_albedo.p;

@@ -93,6 +93,7 @@ struct FrameDev {
     const uint32_t* guide_y;
     fovpt_float4* accum;
     uint32_t* frame;
+    fovpt_float4 *g_normal, *g_color, *g_albedo;   // denoiser guide targets (null unless write_guides)
     uint32_t total_slots;
     int32_t max_depth;
     int32_t accumulate;
@@ -110,6 +111,8 @@ struct PathState {
                         // indirectLight = terms 1.. summed in order); one writer per cell
     size_t stride;      // cells per slot (= max_depth)
     float4* alpha;      // prd.alpha contribution of a shadow-catcher primary hit
+    float4* guide_n;    // write_guides: prd.normal of the primary hit (deviceProgram.cu:509-512), else null
+    float4* guide_a;    // write_guides: prd.albedo of the primary hit
     float4* backplate;  // per launch record: backplate of the last sample (deviceProgram.cu:495)
 };
 

@@ -505,6 +505,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, Pat
             for (int dd = 0; dd < fd.max_depth; dd++)                          // directLight / indirectLight terms, :450-451
                 ps.rad[(size_t)slot * ps.stride + dd] = make_float4(0.f, 0.f, 0.f, 0.f);
             ps.alpha[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ps.guide_n) { ps.guide_n[slot] = make_float4(0.f, 0.f, 0.f, 0.f); ps.guide_a[slot] = make_float4(0.f, 0.f, 0.f, 0.f); }
             if (s == P.spp - 1) {                                               // backplate of the last sample, :495
                 float u, v;
                 probe_dir_to_uv(dir, u, v);
@@ -842,6 +843,10 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
                         const float tcy = (w0 * t0.y + hit.y * t1.y) + hit.z * t2.y;
                         albedo = v3(tex2d(sc.textures[M.texture_id], tcx, tcy));
                     }
+                    if (ps.guide_n && depth == 0 && (flags & FLAG_SECONDARY) == 0) {       // :509-512, :653-654
+                        ps.guide_n[slot] = f4(N, 0.f);
+                        ps.guide_a[slot] = f4(albedo, 0.f);
+                    }
                     float outEta;
                     if (rayEta == 1.0f)                                                    // :673-683
                         outEta = (mat.eta == 0.0f) ? 2.0f / (1.0f - sqrtf(0.08f * mat.specular)) - 1.0f : mat.eta;
@@ -1019,6 +1024,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_resolve(const FrameDev fd, Path
     __shared__ uint32_t s_list_p[FOVPT_BLOCK];     // ... and pass
     __shared__ float4 s_accum[FOVPT_BLOCK];        // result per list entry: accum_color (pre-blend)
     __shared__ uint32_t s_rgba[FOVPT_BLOCK];       // result per list entry: tone-mapped pixel
+    __shared__ float4 s_gn[FOVPT_BLOCK], s_ga[FOVPT_BLOCK];   // denoiser guides per list entry
     __shared__ uint32_t s_wave[4];
 
     const uint32_t tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -1078,9 +1084,10 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_resolve(const FrameDev fd, Path
         const PassDev& P = fd.pass[s_list_p[threadIdx.x]];
         const uint32_t li = s_list_li[threadIdx.x];
         const uint32_t s0 = P.slot_base + li * P.spp;
-        V3 result = v3(0.0f), alpha = v3(0.0f);
+        V3 result = v3(0.0f), alpha = v3(0.0f), gnorm = v3(0.0f), galb = v3(0.0f);
         for (uint32_t s = 0; s < P.spp; s++) {                                     // :536-537, in sample order
             const uint32_t slot = s0 + s;
+            if (ps.guide_n) { gnorm = gnorm + v3(ps.guide_n[slot]); galb = galb + v3(ps.guide_a[slot]); }   // :510-511
             const float4* cells = ps.rad + (size_t)slot * ps.stride;                 // one 16*D-byte record per slot
             const V3 direct = v3(0.0f) + v3(cells[0]);                                // :523
             V3 indirect = v3(0.0f);
@@ -1091,10 +1098,11 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_resolve(const FrameDev fd, Path
             alpha = alpha + (one ? v3(1.0f) : v3(ps.alpha[slot]));
         }
         const float sppf = (float)P.spp;
-        { const float inv = 1.0f / sppf; alpha = alpha * inv; }                    // :543
+        { const float inv = 1.0f / sppf; alpha = alpha * inv; gnorm = gnorm * inv; galb = galb * inv; }   // :541-543
         const V3 backplate = v3(ps.backplate[P.launch_base + li]);
         const V3 color = (backplate * sppf) * sub_sv(1.0f, alpha) + result;        // :558
         const V3 accum_color = div_vs(color, sppf);                                // :560
+        s_gn[threadIdx.x] = f4(gnorm, 1.0f); s_ga[threadIdx.x] = f4(galb, 1.0f);
         s_accum[threadIdx.x] = f4(accum_color, 1.0f);
         s_rgba[threadIdx.x] = make_color(reinhard(accum_color * 16.0f, 1.0f));     // :586,597
     }
@@ -1120,6 +1128,12 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_resolve(const FrameDev fd, Path
         }
         fd.accum[image_index] = fovpt_float4{a.x, a.y, a.z, 1.0f};                 // :582
         fd.frame[image_index] = rgba;
+        if (ps.guide_n) {                                                          // :612-614
+            const float4 gn = s_gn[e], ga = s_ga[e];
+            if (fd.g_normal) fd.g_normal[image_index] = fovpt_float4{gn.x, gn.y, gn.z, 1.0f};
+            if (fd.g_color) fd.g_color[image_index] = fovpt_float4{a.x, a.y, a.z, 1.0f};
+            if (fd.g_albedo) fd.g_albedo[image_index] = fovpt_float4{ga.x, ga.y, ga.z, 1.0f};
+        }
     } else if (state == 2 || (fd.world > 1 && fd.rank != 0)) {
         // another rank's pixel (or nobody's, on a rank other than 0): zero keeps the sum-gather exact
         fd.accum[image_index] = fovpt_float4{0.f, 0.f, 0.f, 0.f};

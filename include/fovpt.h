@@ -158,7 +158,9 @@ typedef struct fovpt_config {
     int32_t tile_w, tile_h;     /* launch-index tile, default 8 x 4
                                    (sutil/WorkDistribution.h:47-84 scheme)         */
     int32_t profile;            /* 1 = time each kernel with hipEvents             */
-    int32_t sort_rays;          /* reserved                                        */
+    int32_t write_guides;       /* 1 = also write normal/color/albedo_buffer, the denoiser guides of
+                                   PT_sv/deviceProgram.cu:555-557 (commented out in PT_sv5_, :612-614);
+                                   not available with shadow-catcher materials         */
     int32_t reserved[1];
 } fovpt_config;
 

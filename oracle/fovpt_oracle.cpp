@@ -735,6 +735,7 @@ struct Opts {
     int accumulate;      // PT_sv4_vmv2/deviceProgram.cu:545-553
     int brute;
     int nthreads;
+    int write_guides;    // PT_sv/deviceProgram.cu:555-557 (commented out in PT_sv5_/deviceProgram.cu:612-614)
 };
 struct Counters {
     std::atomic<uint64_t> radiance_rays{0}, shadow_rays{0}, paths{0};
@@ -891,6 +892,8 @@ void raygen(const Ctx& C, uint32_t lx, uint32_t ly)
     idx[2] = idx[2] * params.frame.factor.z + 0;
     float range = length(mk3((float)idx[0], (float)idx[1], (float)idx[2]) - mk3((float)params.frame.c.x, (float)params.frame.c.y, 0.0f));   // :435
     if (range < params.frame.r_inner || range > params.frame.r_outer) return;       // :437
+    f3 normal = mk3(0.f);                                                           // :443-444 denoiser guides
+    f3 albedo = mk3(0.f);
     f3 alpha = mk3(0.f);
     f3 backplate = mk3(0.f);
     uint64_t nrad = 0, nshadow = 0, npaths = 0;
@@ -919,6 +922,10 @@ void raygen(const Ctx& C, uint32_t lx, uint32_t ly)
         for (;;) {
             prd.radiance = mk3(0.f);
             traceRadiance(C, ray_origin, ray_direction, &prd, nrad, nshadow);       // :501
+            if (prd.depth == 0.f) {                                                 // :509-512
+                normal += prd.normal;
+                albedo += prd.albedo;
+            }
             if ((prd.stateFlags & RAY_STATE_FLAGS_DONE) || prd.depth >= C.opt.max_depth) break;   // :515
             if (prd.depth == 0) directLight += prd.radiance;
             else indirectLight += prd.radiance;
@@ -930,6 +937,8 @@ void raygen(const Ctx& C, uint32_t lx, uint32_t ly)
         alpha += prd.alpha;
     } while (--i);
     C.cnt->radiance_rays += nrad; C.cnt->shadow_rays += nshadow; C.cnt->paths += npaths;
+    normal /= static_cast<float>(samples_per_launch);                               // :541-542
+    albedo /= static_cast<float>(samples_per_launch);
     alpha /= static_cast<float>(samples_per_launch);                                // :543
 
     for (int fi = 0; fi < params.frame.fillSize; ++fi) {                            // :546-616
@@ -953,6 +962,11 @@ void raygen(const Ctx& C, uint32_t lx, uint32_t ly)
             params.frame.accum_buffer[image_index] = out;                           // :582
             f3 exposed = accum_color * 16.0f;                                       // :586 pow(2.0f, 4.0f)
             params.frame.frame_buffer[image_index] = make_color(reinhardToneMap(exposed, 1.0f));   // :597
+            if (C.opt.write_guides) {                                               // :612-614 (live in PT_sv/deviceProgram.cu:555-557)
+                if (params.frame.normal_buffer) { fovpt_float4 v = {normal.x, normal.y, normal.z, 1.0f}; params.frame.normal_buffer[image_index] = v; }
+                if (params.frame.color_buffer) { fovpt_float4 v = {accum_color.x, accum_color.y, accum_color.z, 1.0f}; params.frame.color_buffer[image_index] = v; }
+                if (params.frame.albedo_buffer) { fovpt_float4 v = {albedo.x, albedo.y, albedo.z, 1.0f}; params.frame.albedo_buffer[image_index] = v; }
+            }
         }
     }
 }
@@ -1051,17 +1065,21 @@ void orc_scene_destroy(void* s) { delete (Scene*)s; }
 uint64_t orc_scene_num_triangles(void* s) { return ((Scene*)s)->tris.size(); }
 
 /* optixLaunch equivalent; lp carries HOST pointers (frame buffers, probe arrays). counters[3] += {radiance, shadow, paths} */
-int orc_launch(void* scene, const fovpt_launch_params* lp, uint32_t width, uint32_t height,
-               int max_depth, int accumulate, int brute, int nthreads, uint64_t* counters)
+int orc_launch2(void* scene, const fovpt_launch_params* lp, uint32_t width, uint32_t height,
+                int max_depth, int accumulate, int brute, int nthreads, int write_guides, uint64_t* counters)
 {
     if (!scene || !lp || !lp->frame.accum_buffer || !lp->frame.frame_buffer || !lp->probe.data) return FOVPT_E_INVALID;
     if (lp->samples_per_launch == 0) return FOVPT_E_INVALID;     // do{}while(--i) needs spp >= 1 (:448,539)
-    Opts o; o.max_depth = max_depth; o.accumulate = accumulate; o.brute = brute; o.nthreads = nthreads;
+    Opts o; o.max_depth = max_depth; o.accumulate = accumulate; o.brute = brute; o.nthreads = nthreads; o.write_guides = write_guides;
     Counters c;
     launch(*(Scene*)scene, *lp, width, height, o, c);
     if (counters) { counters[0] += c.radiance_rays; counters[1] += c.shadow_rays; counters[2] += c.paths; }
     return 0;
 }
+
+int orc_launch(void* scene, const fovpt_launch_params* lp, uint32_t width, uint32_t height,
+               int max_depth, int accumulate, int brute, int nthreads, uint64_t* counters)
+{ return orc_launch2(scene, lp, width, height, max_depth, accumulate, brute, nthreads, 0, counters); }
 
 /* SampleRenderer::render(), SimplePathtracer.cpp:77-214, with the #defines turned into cfg fields */
 int orc_render(void* scene, fovpt_launch_params* lp, const fovpt_config* cfg, int brute, int nthreads, uint64_t* counters)
@@ -1081,7 +1099,7 @@ int orc_render(void* scene, fovpt_launch_params* lp, const fovpt_config* cfg, in
         L.frame.redraw = 0;
         L.viewportSize.x = L.frame.size.x; L.viewportSize.y = L.frame.size.y;
         int temp_frame = (int)L.frame.subframe_index;
-        rc = orc_launch(scene, &L, (uint32_t)L.frame.size.x, (uint32_t)L.frame.size.y, cfg->max_depth, cfg->accumulate, brute, nthreads, counters);
+        rc = orc_launch2(scene, &L, (uint32_t)L.frame.size.x, (uint32_t)L.frame.size.y, cfg->max_depth, cfg->accumulate, brute, nthreads, cfg->write_guides, counters);
         L.frame.subframe_index = (uint32_t)temp_frame;
         L.frame.subframe_index++;
         return rc;
@@ -1095,7 +1113,7 @@ int orc_render(void* scene, fovpt_launch_params* lp, const fovpt_config* cfg, in
     L.samples_per_launch = (uint32_t)cfg->spp_periphery;
     L.frame.offset = mk_u2(0, 0);
     L.frame.redraw = 0;
-    rc = orc_launch(scene, &L, (uint32_t)(L.frame.size.x / 4), (uint32_t)(L.frame.size.y / 4), cfg->max_depth, cfg->accumulate, brute, nthreads, counters);
+    rc = orc_launch2(scene, &L, (uint32_t)(L.frame.size.x / 4), (uint32_t)(L.frame.size.y / 4), cfg->max_depth, cfg->accumulate, brute, nthreads, cfg->write_guides, counters);
     if (rc) return rc;
     // intermediate :160-187
     int temp_frame = (int)L.frame.subframe_index;
@@ -1107,7 +1125,7 @@ int orc_render(void* scene, fovpt_launch_params* lp, const fovpt_config* cfg, in
     L.samples_per_launch = (uint32_t)cfg->spp_middle;
     L.frame.offset = mk_u2(L.frame.c.x - (uint32_t)(outer_radius + 2), L.frame.c.y - (uint32_t)(outer_radius + 2));
     L.frame.redraw = 1;
-    rc = orc_launch(scene, &L, (uint32_t)L.frame.r_outer, (uint32_t)L.frame.r_outer, cfg->max_depth, cfg->accumulate, brute, nthreads, counters);
+    rc = orc_launch2(scene, &L, (uint32_t)L.frame.r_outer, (uint32_t)L.frame.r_outer, cfg->max_depth, cfg->accumulate, brute, nthreads, cfg->write_guides, counters);
     if (rc) return rc;
     // fovea :189-209
     L.frame.factor = mk_u3(1, 1, 1);
@@ -1117,7 +1135,7 @@ int orc_render(void* scene, fovpt_launch_params* lp, const fovpt_config* cfg, in
     L.samples_per_launch = (uint32_t)cfg->spp_fovea;
     L.frame.offset = mk_u2(L.frame.c.x - (uint32_t)(inner_radius + 1), L.frame.c.y - (uint32_t)(inner_radius + 1));
     L.frame.redraw = 1;
-    rc = orc_launch(scene, &L, (uint32_t)(L.frame.r_outer * 2), (uint32_t)(L.frame.r_outer * 2), cfg->max_depth, cfg->accumulate, brute, nthreads, counters);
+    rc = orc_launch2(scene, &L, (uint32_t)(L.frame.r_outer * 2), (uint32_t)(L.frame.r_outer * 2), cfg->max_depth, cfg->accumulate, brute, nthreads, cfg->write_guides, counters);
     L.frame.subframe_index = (uint32_t)temp_frame;
     L.frame.subframe_index++;
     return rc;

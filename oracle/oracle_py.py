@@ -120,10 +120,16 @@ class OracleFrame:
         self.w, self.h = width, height
         self.accum = np.zeros((height, width, 4), np.float32)
         self.frame = np.zeros((height, width), np.uint32)
+        self.normal = np.zeros((height, width, 4), np.float32)
+        self.color = np.zeros((height, width, 4), np.float32)
+        self.albedo = np.zeros((height, width, 4), np.float32)
         self.probe = probe
         lp = abi.LaunchParams()
         lp.frame.accum_buffer = self.accum.ctypes.data
         lp.frame.frame_buffer = self.frame.ctypes.data
+        lp.frame.normal_buffer = self.normal.ctypes.data
+        lp.frame.color_buffer = self.color.ctypes.data
+        lp.frame.albedo_buffer = self.albedo.ctypes.data
         lp.frame.size.x, lp.frame.size.y = width, height
         lp.frame.subframe_index = subframe_index
         gx, gy = gaze if gaze is not None else (width // 2, height // 2)

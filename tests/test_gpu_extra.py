@@ -135,6 +135,28 @@ def test_shadow_catcher_material(oracle):
     r.close()
 
 
+def test_denoiser_guide_buffers(oracle):
+    """write_guides: normal / color / albedo buffers as PT_sv/deviceProgram.cu:555-557 wrote them
+    (first-hit normal and albedo averaged over the samples; commented out in PT_sv5_)."""
+    model, probe, size = scenes.atrium(8000), scenes.ambient_probe(96, 54, 2.5), (192, 108)
+    cfg = cfg_foveated(15, 48, (1, 2, 8))
+    cfg.write_guides = 1
+    r = make_gpu(model, probe, scenes.ATRIUM_CAMERA, size, cfg)
+    r.render()
+    f = r.launchParams.frame
+    got = [r.download(ptr, np.empty((size[1], size[0], 4), np.float32)) for ptr in (f.normal_buffer, f.color_buffer, f.albedo_buffer)]
+    ga = r.downloadAccum()
+    r.close()
+    S, F = make_oracle(oracle, model, probe, scenes.ATRIUM_CAMERA, size)
+    oracle.render(S, F, cfg)
+    assert _bits_equal(ga, F.accum)
+    for g, o in zip(got, (F.normal, F.color, F.albedo)):
+        assert _bits_equal(g, o)
+    assert _bits_equal(got[1], ga)                                        # color_buffer == accum_buffer
+    n = np.linalg.norm(got[0][..., :3], axis=-1)
+    assert ((n > 0.99) & (n < 1.01)).mean() > 0.3                          # 1-spp periphery pixels carry unit normals
+
+
 def test_two_rank_tile_shards_sum_to_the_full_frame():
     """fovpt_config.rank/world: the shards are disjoint, zero elsewhere, and add up bit-exactly."""
     model, probe, size = scenes.atrium(8000), scenes.ambient_probe(96, 54, 2.5), (192, 108)
