@@ -495,6 +495,52 @@ int fovpt_set_probe(fovpt_ctx* c, int width, int height, const fovpt_float4* dat
     return FOVPT_OK;
 }
 
+int fovpt_set_probe_data(fovpt_ctx* c, int width, int height, const fovpt_float4* data, const fovpt_float3* offset, fovpt_probe* out)
+{
+    if (!c) return FOVPT_E_INVALID;
+    if (!data || width <= 0 || height <= 0 || !out) return fail(c, FOVPT_E_INVALID, "Probe Data is not valid");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
+    const size_t n = (size_t)width * height;
+    HIPCHK(c, c->pr_pdfx.reserve(n * 4)); HIPCHK(c, c->pr_cdfx.reserve(n * 4));
+    HIPCHK(c, c->pr_pdfy.reserve((size_t)height * 4)); HIPCHK(c, c->pr_cdfy.reserve((size_t)height * 4));
+    HIPCHK(c, c->pr_data.reserve(n * 16));
+    HIPCHK(c, hipMemcpy(c->pr_data.p, data, n * 16, hipMemcpyHostToDevice));
+    DevBuf row_total;
+    HIPCHK(c, row_total.reserve((size_t)height * 4));
+    fovpt_launch_build_cdf(c->stream, width, height, (const float4*)c->pr_data.p, (float*)c->pr_pdfx.p, (float*)c->pr_cdfx.p,
+                           (float*)c->pr_pdfy.p, (float*)c->pr_cdfy.p, (float*)row_total.p);
+    // monotonicity decides whether the guide tables may be used; check on the host copy of the result
+    std::vector<float> hx(n), hy((size_t)height);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    row_total.release();
+    HIPCHK(c, hipMemcpy(hx.data(), c->pr_cdfx.p, n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(hy.data(), c->pr_cdfy.p, (size_t)height * 4, hipMemcpyDeviceToHost));
+    bool sorted = true;
+    for (int row = 0; row < height && sorted; row++) {
+        const float* cr = hx.data() + (size_t)row * width;
+        for (int k = 1; k < width; k++) if (!(cr[k] >= cr[k - 1])) { sorted = false; break; }
+    }
+    for (int k = 1; k < height && sorted; k++) if (!(hy[k] >= hy[k - 1])) sorted = false;
+    c->guide_ok = false;
+    if (sorted) {
+        HIPCHK(c, c->pr_guidex.reserve((size_t)height * (width + 2) * 4));
+        HIPCHK(c, c->pr_guidey.reserve((size_t)(height + 2) * 4));
+        fovpt_launch_build_guide(c->stream, (const float*)c->pr_cdfx.p, width, height, (uint32_t*)c->pr_guidex.p);
+        fovpt_launch_build_guide(c->stream, (const float*)c->pr_cdfy.p, height, 1, (uint32_t*)c->pr_guidey.p);
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->guide_ok = true; c->guide_w = width; c->guide_h = height;
+    }
+    memset(out, 0, sizeof(*out));
+    out->width = width; out->height = height;
+    out->data = (fovpt_float4*)c->pr_data.p;
+    out->pdfValuesX = (float*)c->pr_pdfx.p; out->cdfValuesX = (float*)c->pr_cdfx.p;
+    out->pdfValuesY = (float*)c->pr_pdfy.p; out->cdfValuesY = (float*)c->pr_cdfy.p;
+    if (offset) out->offset = *offset;
+    return FOVPT_OK;
+}
+
 int fovpt_resize(fovpt_ctx* c, int width, int height, fovpt_frame_ptrs* out)
 {
     if (!c) return FOVPT_E_INVALID;

@@ -1153,6 +1153,45 @@ __global__ void k_build_guide(const float* __restrict__ cdf, int n, int segments
     guide[i] = (uint32_t)(lower_bound(cdf, seg * n, (seg + 1) * n, value) - seg * n);
 }
 
+// ---- ProbeData::BuildCDF on the device (Probe.h:29-77) -----------------------------------------
+// fp32 sums are not associative and the reference accumulates strictly left to right, so the
+// parallelism is across rows only: one thread walks one row in order; a single thread then walks
+// the row totals.  Same bits as the host helper fovpt_probe_build_cdf.
+__global__ void k_cdf_rows(int w, int h, const float4* __restrict__ data, float* __restrict__ pdfX, float* __restrict__ cdfX,
+                           float* __restrict__ row_total)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= h) return;
+    float totalWeightX = 0.0f;
+    for (int i = 0; i < w; ++i) {
+        const float4 c = data[(size_t)j * w + i];
+        const float weight = c.x * 0.3f + c.y * 0.6f + c.z * 0.1f;          // Luminance, maths.h:165-168
+        totalWeightX += weight;
+        pdfX[(size_t)j * w + i] = weight;
+        cdfX[(size_t)j * w + i] = totalWeightX;
+    }
+    const float invTotalWeightX = 1.0f / totalWeightX;
+    for (int i = 0; i < w; ++i) {
+        pdfX[(size_t)j * w + i] *= invTotalWeightX;
+        cdfX[(size_t)j * w + i] *= invTotalWeightX;
+    }
+    row_total[j] = totalWeightX;
+}
+__global__ void k_cdf_cols(int h, const float* __restrict__ row_total, float* __restrict__ pdfY, float* __restrict__ cdfY)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    float totalWeightY = 0.0f;
+    for (int j = 0; j < h; ++j) {
+        totalWeightY += row_total[j];
+        pdfY[j] = row_total[j];
+        cdfY[j] = totalWeightY;
+    }
+    for (int j = 0; j < h; ++j) {
+        cdfY[j] /= totalWeightY;
+        pdfY[j] /= totalWeightY;
+    }
+}
+
 // ---- device self-test --------------------------------------------------------------------
 __global__ void k_math(int op, const float* a, const float* b, float* out, size_t n)
 {
@@ -1199,6 +1238,11 @@ void fovpt_launch_build_guide(hipStream_t st, const float* cdf, int n, int segme
 {
     const size_t total = (size_t)segments * (n + 2);
     hipLaunchKernelGGL(k_build_guide, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, cdf, n, segments, guide);
+}
+void fovpt_launch_build_cdf(hipStream_t st, int w, int h, const float4* data, float* pdfX, float* cdfX, float* pdfY, float* cdfY, float* row_total)
+{
+    hipLaunchKernelGGL(k_cdf_rows, dim3((h + 63) / 64), dim3(64), 0, st, w, h, data, pdfX, cdfX, row_total);
+    hipLaunchKernelGGL(k_cdf_cols, dim3(1), dim3(64), 0, st, h, row_total, pdfY, cdfY);
 }
 void fovpt_launch_math(hipStream_t st, int op, const float* a, const float* b, float* out, size_t n)
 {

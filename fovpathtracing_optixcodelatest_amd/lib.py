@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 SO_PATH = os.environ.get("FOVPT_SO") or os.path.join(CSRC, "libfovpt.so")   # FOVPT_SO: A/B builds of the same library
 
 EXPORTS = [
-    "fovpt_create", "fovpt_destroy", "fovpt_last_error", "fovpt_set_scene", "fovpt_set_probe",
+    "fovpt_create", "fovpt_destroy", "fovpt_last_error", "fovpt_set_scene", "fovpt_set_probe", "fovpt_set_probe_data",
     "fovpt_resize", "fovpt_get_config", "fovpt_set_config", "fovpt_launch", "fovpt_render",
     "fovpt_synchronize", "fovpt_download", "fovpt_get_stats", "fovpt_reset_stats", "fovpt_stream",
     "fovpt_probe_build_cdf", "fovpt_camera_uvw", "fovpt_debug_math", "fovpt_debug_buffer",
@@ -55,6 +55,7 @@ def load():
     L.fovpt_last_error.restype = C.c_char_p
     L.fovpt_set_scene.argtypes = [vp, vp, i32, vp, i32, C.POINTER(u64)]
     L.fovpt_set_probe.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(abi.Probe)]
+    L.fovpt_set_probe_data.argtypes = [vp, i32, i32, vp, vp, C.POINTER(abi.Probe)]
     L.fovpt_resize.argtypes = [vp, i32, i32, C.POINTER(abi.FramePtrs)]
     L.fovpt_get_config.argtypes = [vp, C.POINTER(abi.Config)]
     L.fovpt_set_config.argtypes = [vp, C.POINTER(abi.Config)]

@@ -208,6 +208,17 @@ class SampleRenderer:
                                             C.byref(off), C.byref(out)))
         self.launchParams.probe = out
 
+    def setProbeData(self, data, offset=(0.0, 0.0, 0.0)):
+        """loadColor / loadProbe + BuildCDF + setProbe in one step (main.cpp:161-187, 306), with BuildCDF
+        run on the device (fovpt_set_probe_data).  Returns the device-side tables for inspection."""
+        data = np.ascontiguousarray(data, np.float32)
+        h, w = data.shape[:2]
+        off = abi.Float3().set(offset)
+        out = abi.Probe()
+        self._check(self._L.fovpt_set_probe_data(self._ctx, w, h, data.ctypes.data, C.byref(off), C.byref(out)))
+        self.launchParams.probe = out
+        return out
+
     def debug_math(self, op, a, b=None):
         a = np.ascontiguousarray(a, np.float32)
         bb = np.ascontiguousarray(b, np.float32) if b is not None else None

@@ -206,6 +206,12 @@ int fovpt_set_probe(fovpt_ctx* ctx, int width, int height, const fovpt_float4* d
                     const float* pdfValuesY, const float* cdfValuesY,
                     const fovpt_float3* offset, fovpt_probe* probe_out);
 
+/* The same, with ProbeData::BuildCDF (Probe.h:29-77) done on the device: uploads only the texels and
+ * builds pdf/cdf tables in HBM with the reference's left-to-right fp32 summation order (rows in
+ * parallel).  Bit-identical to fovpt_probe_build_cdf + fovpt_set_probe.                          */
+int fovpt_set_probe_data(fovpt_ctx* ctx, int width, int height, const fovpt_float4* data,
+                         const fovpt_float3* offset, fovpt_probe* probe_out);
+
 /* SampleRenderer::resize (SimplePathtracer.cpp:228-274): (re)allocates the five
  * full-frame buffers.  No-op returning FOVPT_OK with *out untouched when w or h is 0. */
 int fovpt_resize(fovpt_ctx* ctx, int width, int height, fovpt_frame_ptrs* out);

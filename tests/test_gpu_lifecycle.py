@@ -123,3 +123,19 @@ def test_hdr_probe_and_non_monotone_cdf_fallback(oracle):
     oracle.render(S, F, cfg)
     assert _eq(r.downloadAccum(), F.accum)
     r.close()
+
+
+def test_build_cdf_on_device_matches_host_and_oracle(oracle):
+    """fovpt_set_probe_data: ProbeData::BuildCDF on the GPU, rows in parallel, left-to-right within a row."""
+    for data in (scenes.sky_probe(96, 40, seed=3), scenes.ambient_probe(320, 180, 2.5)):
+        h, w = data.shape[:2]
+        r = renderer.SampleRenderer(scenes.cornell_box())
+        p = r.setProbeData(data)
+        got = [r.download(ptr, np.empty(shape, np.float32)) for ptr, shape in
+               ((p.pdfValuesX, (h, w)), (p.cdfValuesX, (h, w)), (p.pdfValuesY, (h,)), (p.cdfValuesY, (h,)))]
+        r.close()
+        host = renderer.ProbeData(data).BuildCDF()
+        want = (host.pdfValuesX, host.cdfValuesX, host.pdfValuesY, host.cdfValuesY)
+        ora = oracle.build_cdf(data)
+        for g, hst, o in zip(got, want, ora):
+            assert _eq(g, hst) and _eq(g, o)
