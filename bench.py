@@ -80,11 +80,19 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); none visible")
+    # FOVPT_BENCH_REHEARSAL=1: all ranks share device 0 and talk over gloo -- a logic rehearsal of the
+    # N > 1 path on a one-GPU box (RCCL refuses two ranks on one device); numbers are meaningless
+    rehearsal = os.environ.get("FOVPT_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
 
     from fovpathtracing_optixcodelatest_amd import abi, renderer, scenes
     from fovpathtracing_optixcodelatest_amd import multigpu
@@ -110,29 +118,38 @@ def main():
     # them at N > 1: the RCCL reduce-gather of frame k runs beside the rendering of frame k+1.
     frames = [torch.zeros(H * W, dtype=torch.int32, device="cuda") for _ in range(2 if world > 1 else 1)]
     pending = [None, None]
+    sync_gather = rehearsal
     step_no = [0]
+
+    # torch's view of the library's main stream: collectives issued under it are ordered after the
+    # frame on the device, so the loop needs no host synchronisation (the host runs ahead)
+    lib_stream = torch.cuda.ExternalStream(r.stream, device=torch.device("cuda", local_rank))
 
     def step():
         k = step_no[0] % len(frames)
         step_no[0] += 1
-        if pending[k] is not None:                             # the gather that last used this buffer
-            pending[k].wait()                                  # orders torch's stream after the RCCL op ...
-            torch.cuda.current_stream().synchronize()          # ... and the host (the library has its own stream)
-            pending[k] = None
-        # the shipped app resets subframe_index to 0 before every render() (main.cpp:402-407)
-        r.launchParams.frame.subframe_index = 0
-        r.launchParams.frame.frame_buffer = frames[k].data_ptr()
-        r.render_async()
-        if world > 1:
-            r.synchronize()                                    # library stream -> RCCL stream hand-off
-            pending[k] = multigpu.gather_frame(frames[k], dst=0, async_op=True)
+        with torch.cuda.stream(lib_stream):
+            if pending[k] is not None:                         # the gather that last used this buffer:
+                pending[k].wait()                              # the library's stream waits for it (device side)
+                pending[k] = None
+            # the shipped app resets subframe_index to 0 before every render() (main.cpp:402-407)
+            r.launchParams.frame.subframe_index = 0
+            r.launchParams.frame.frame_buffer = frames[k].data_ptr()
+            r.render_async()
+            if world > 1 and not sync_gather:                  # RCCL waits for the frame, then reduces beside frame k+1
+                pending[k] = multigpu.gather_frame(frames[k], dst=0, async_op=True)
+        if world > 1 and sync_gather:                          # gloo (rehearsal) knows nothing about HIP streams
+            r.synchronize()
+            multigpu.gather_frame(frames[k], dst=0)
 
     def fence():
         r.synchronize()
-        for k in range(len(pending)):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
+        with torch.cuda.stream(lib_stream):
+            for k in range(len(pending)):
+                if pending[k] is not None:
+                    pending[k].wait()
+                    pending[k] = None
+        lib_stream.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
@@ -146,6 +163,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    last_frame_host = frames[(step_no[0] - 1) % len(frames)].cpu()      # rank 0: the gathered frame
     st = r.stats()
     rays_local = float(st.radiance_rays + st.shadow_rays)
     if world > 1:
@@ -254,9 +272,20 @@ def main():
         }
         # the timed frames are parity frames too: the oracle just rendered the same frame
         import numpy as np
-        gpu_px = frames[(step_no[0] - 1) % len(frames)].cpu().numpy().view(np.uint32).reshape(H, W)
+        gpu_px = last_frame_host.numpy().view(np.uint32).reshape(H, W)
         out["parity_vs_oracle_rgba8_mismatch"] = int((gpu_px != F.frame).sum())
 
+    if world > 1 and rank == 0 and os.environ.get("FOVPT_BENCH_CHECK") == "1":
+        # the gathered frame on rank 0 must be the unsharded frame, bit for bit
+        gathered = last_frame_host
+        c1 = cfg.copy()
+        c1.rank, c1.world, c1.profile = 0, 1, 0
+        r.config = c1
+        solo = torch.zeros(H * W, dtype=torch.int32, device="cuda")
+        r.launchParams.frame.subframe_index = 0
+        r.launchParams.frame.frame_buffer = solo.data_ptr()
+        r.render()
+        out["gather_mismatch_vs_single_gpu"] = int((gathered != solo.cpu()).sum())
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

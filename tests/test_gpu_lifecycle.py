@@ -139,3 +139,50 @@ def test_build_cdf_on_device_matches_host_and_oracle(oracle):
         ora = oracle.build_cdf(data)
         for g, hst, o in zip(got, want, ora):
             assert _eq(g, hst) and _eq(g, o)
+
+
+def test_torch_external_stream_orders_after_the_frame():
+    """bench.py hands the frame to torch.distributed under torch.cuda.ExternalStream(library stream): work
+    queued on that stream must see the finished frame without any host synchronisation."""
+    import torch
+    size = (256, 144)
+    r = make_gpu(scenes.atrium(8000), scenes.ambient_probe(64, 36, 2.5), scenes.ATRIUM_CAMERA, size, cfg_foveated(20, 64, (1, 2, 8)))
+    frame = torch.zeros(size[0] * size[1], dtype=torch.int32, device="cuda")
+    ext = torch.cuda.ExternalStream(r.stream)
+    copies = []
+    for _ in range(3):
+        r.launchParams.frame.subframe_index = 0
+        r.launchParams.frame.frame_buffer = frame.data_ptr()
+        with torch.cuda.stream(ext):
+            r.render_async()
+            copies.append(frame.clone())           # enqueued right behind the frame, on the same stream
+            frame.zero_()                          # and the buffer is recycled at once
+    ext.synchronize()
+    r.launchParams.frame.subframe_index = 0
+    r.render()
+    want = torch.from_numpy(r.download(frame.data_ptr(), np.empty(size[0] * size[1], np.int32)))
+    for c in copies:
+        assert torch.equal(c.cpu(), want)
+    assert int((want != 0).sum()) > 0.9 * want.numel()
+    r.close()
+
+
+def test_bench_two_rank_rehearsal_gathers_the_full_frame():
+    """bench.py's N > 1 path end to end on ONE GPU: two ranks share device 0 and talk over gloo
+    (FOVPT_BENCH_REHEARSAL; RCCL refuses two ranks per device).  Rank 0's gathered frame must equal the
+    unsharded frame bit for bit."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FOVPT_BENCH_REHEARSAL="1", FOVPT_BENCH_CHECK="1", MASTER_ADDR="127.0.0.1")
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "6", "--warmup", "2"], capture_output=True, text=True, env=env, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["gather_mismatch_vs_single_gpu"] == 0
+    assert out["config"]["rays_per_frame"] > 3.0e6        # both ranks' rays are counted
