@@ -91,6 +91,7 @@ struct FrameDev {
     fovpt_probe probe;            // device pointers
     const uint32_t* guide_x;      // lower_bound guide tables for probe.cdfValuesX / Y, or null
     const uint32_t* guide_y;
+    int32_t probe_row_mul;        // 0 when all probe rows are identical (constant ambient probe), else 1
     fovpt_float4* accum;
     uint32_t* frame;
     fovpt_float4 *g_normal, *g_color, *g_albedo;   // denoiser guide targets (null unless write_guides)

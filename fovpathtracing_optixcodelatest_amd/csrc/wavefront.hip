@@ -118,11 +118,14 @@ __device__ inline void probe_dir_to_uv(const V3& dir, float& u, float& v)     //
     u = (kPi + phi) * kInvPi * 0.5f;
     v = theta * kInvPi;
 }
-__device__ inline float4 probe_eval(const fovpt_probe& pr, float u, float v)  // :61-67
+// row_mul is 1, or 0 when every row of the probe (texels and row tables) is bit-identical to row 0 -- the
+// reference's shipped lighting is such a probe (loadColor, main.cpp:175-187) -- so that all lookups land in
+// one L1-resident row instead of 8-33 MB of HBM/L2.  Same values either way.
+__device__ inline float4 probe_eval(const fovpt_probe& pr, int row_mul, float u, float v)  // :61-67
 {
     int px = max(0, min((int)(u * pr.width), pr.width - 1));
     int py = max(0, min((int)(v * pr.height), pr.height - 1));
-    return ((const float4*)pr.data)[py * pr.width + px];
+    return ((const float4*)pr.data)[py * row_mul * pr.width + px];
 }
 __device__ inline int lower_bound(const float* __restrict__ a, int lower, int upper, float value)   // :119-136
 {
@@ -152,7 +155,7 @@ __device__ inline int lower_bound_guided(const float* __restrict__ a, const uint
     }
     return lower;
 }
-__device__ inline void probe_sample(const fovpt_probe& pr, const uint32_t* __restrict__ guide_x, const uint32_t* __restrict__ guide_y,
+__device__ inline void probe_sample(const fovpt_probe& pr, const uint32_t* __restrict__ guide_x, const uint32_t* __restrict__ guide_y, int row_mul,
                                     V3& dir, V3& color, float& pdf, Rng& rng)   // :138-169
 {
     float r1 = rng.randf01();
@@ -160,13 +163,16 @@ __device__ inline void probe_sample(const fovpt_probe& pr, const uint32_t* __res
     int row, col;
     if (guide_x) {
         row = lower_bound_guided(pr.cdfValuesY, guide_y, 0, pr.height, r1);
-        col = lower_bound_guided(pr.cdfValuesX, guide_x + (size_t)row * (pr.width + 2), row * pr.width, pr.width, r2) - row * pr.width;
+        const int rx = row * row_mul;
+        col = lower_bound_guided(pr.cdfValuesX, guide_x + (size_t)rx * (pr.width + 2), rx * pr.width, pr.width, r2) - rx * pr.width;
     } else {
         row = lower_bound(pr.cdfValuesY, 0, pr.height, r1);
-        col = lower_bound(pr.cdfValuesX, row * pr.width, (row + 1) * pr.width, r2) - row * pr.width;
+        const int rx = row * row_mul;
+        col = lower_bound(pr.cdfValuesX, rx * pr.width, (rx + 1) * pr.width, r2) - rx * pr.width;
     }
-    color = v3(((const float4*)pr.data)[row * pr.width + col]);
-    pdf = pr.pdfValuesX[row * pr.width + col] * pr.pdfValuesY[row];
+    const int rowx = row * row_mul;
+    color = v3(((const float4*)pr.data)[rowx * pr.width + col]);
+    pdf = pr.pdfValuesX[rowx * pr.width + col] * pr.pdfValuesY[row];
     float u = col / float(pr.width);
     float v = row / float(pr.height);
     float sinTheta, cosTheta;
@@ -509,7 +515,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, Pat
             if (s == P.spp - 1) {                                               // backplate of the last sample, :495
                 float u, v;
                 probe_dir_to_uv(dir, u, v);
-                ps.backplate[P.launch_base + ly * P.gw + lx] = probe_eval(fd.probe, u, v);
+                ps.backplate[P.launch_base + ly * P.gw + lx] = probe_eval(fd.probe, fd.probe_row_mul, u, v);
             }
         }
         const uint32_t pos = block_append(cnt->q[0], cap, live, s_scratch);
@@ -854,7 +860,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
                         outEta = 1.0f;
                     // ---- SampleLights / SampleShadow :303-387 with the occlusion test deferred
                     V3 wi, skyColor; float skyPdf;
-                    probe_sample(fd.probe, fd.guide_x, fd.guide_y, wi, skyColor, skyPdf, rng);
+                    probe_sample(fd.probe, fd.guide_x, fd.guide_y, fd.probe_row_mul, wi, skyColor, skyPdf, rng);
                     V3 sum_hit = v3(0.0f);        // value of `sum` on the branch that evaluates the BSDF
                     {
                         const float bsdfPdf = bsdf_pdf(mat, rayEta, outEta, N, wo, wi);
