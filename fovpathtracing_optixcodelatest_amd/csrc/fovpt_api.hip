@@ -63,6 +63,7 @@ struct fovpt_ctx {
     DevBuf s_ray_o, s_ray_d, s_thr, s_rng, s_hit, s_rad, s_alpha, s_backplate, s_guide_n, s_guide_a;
     DevBuf q_a, q_b, sq_o[2], sq_d[2], sq_vis[2], sq_occ[2], counters, spill, spill_shadow;
     int grid = 2048, grid_shadow = 1024;
+    uint64_t slot_budget = 16ull << 20;    // sample slots per wavefront job (~1.3 KB of state and queues each)
     // stats
     fovpt_stats stats;
     std::vector<EventPair> pending;
@@ -171,7 +172,9 @@ int ensure_state(fovpt_ctx* c, size_t slots, size_t launches)
     return FOVPT_OK;
 }
 
-// The engine: all passes of one frame as one wavefront job.
+int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_in, int npass, int chunked);
+
+// The engine: all passes of one frame as one wavefront job (or several, for very large launches).
 int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_in, int npass)
 {
     if (!c->has_scene || lp->traversable != c->scene_id) return fail(c, FOVPT_E_NO_SCENE, "launch without a scene (traversable %llu, current %llu)",
@@ -183,15 +186,56 @@ int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passe
     if (lp->frame.size.x <= 0 || lp->frame.size.y <= 0) return fail(c, FOVPT_E_INVALID, "bad frame size");
     if (c->cfg.max_depth < 1 || c->cfg.max_depth > 32) return fail(c, FOVPT_E_INVALID, "max_depth out of range");
 
+    // A launch whose sample slots would not fit the per-job budget is cut into chunks of launch rows and
+    // run as several jobs in the reference's order (pass by pass, rows ascending): later jobs overwrite
+    // earlier ones exactly as later launch indices overwrite earlier ones in the reference.
+    uint64_t all_slots = 0;
+    for (int p = 0; p < npass; p++) {
+        if (passes_in[p].spp == 0) return fail(c, FOVPT_E_INVALID, "samples_per_launch must be >= 1 (do{}while(--i), deviceProgram.cu:448,539)");
+        all_slots += (uint64_t)passes_in[p].gw * passes_in[p].gh * passes_in[p].spp;
+    }
+    const uint64_t budget = c->slot_budget;
+    if (all_slots > budget) {
+        c->stats.frames++;
+        if (c->cfg.world > 1) {
+            // foreign pixels are written as zero by whichever job wins them; holes must not keep stale sums
+            HIPCHK(c, hipMemsetAsync(lp->frame.frame_buffer, 0, (size_t)lp->frame.size.x * lp->frame.size.y * 4, c->stream));
+            HIPCHK(c, hipMemsetAsync(lp->frame.accum_buffer, 0, (size_t)lp->frame.size.x * lp->frame.size.y * 16, c->stream));
+        }
+        for (int p = 0; p < npass; p++) {
+            const PassDev& P = passes_in[p];
+            const uint64_t per_row = (uint64_t)P.gw * P.spp;
+            if (per_row == 0 || P.gh == 0) continue;
+            if (per_row > budget) return fail(c, FOVPT_E_INVALID, "one launch row needs %llu sample slots (budget %llu)", (unsigned long long)per_row, (unsigned long long)budget);
+            const uint32_t rows_per = (uint32_t)(budget / per_row);
+            for (uint32_t y0 = 0; y0 < P.gh; y0 += rows_per) {
+                PassDev Q = P;
+                Q.row0 = y0; Q.row1 = y0 + rows_per < P.gh ? y0 + rows_per : P.gh;
+                int rc = run_job(c, lp, &Q, 1, 1);
+                if (rc) return rc;
+            }
+        }
+        return FOVPT_OK;
+    }
+    PassDev full[FOVPT_MAX_PASSES];
+    for (int p = 0; p < npass; p++) { full[p] = passes_in[p]; full[p].row0 = 0; full[p].row1 = passes_in[p].gh; }
+    c->stats.frames++;
+    return run_job(c, lp, full, npass, 0);
+}
+
+// One wavefront job: generate -> (closest, shade, occlusion) x depth -> resolve over the given passes / row ranges.
+int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_in, int npass, int chunked)
+{
     FrameDev fd;
     memset(&fd, 0, sizeof(fd));
+    fd.chunked = chunked;
     uint64_t slots = 0, launches = 0;
     for (int p = 0; p < npass; p++) {
         PassDev P = passes_in[p];
-        if (P.spp == 0) return fail(c, FOVPT_E_INVALID, "samples_per_launch must be >= 1 (do{}while(--i), deviceProgram.cu:448,539)");
+        const uint64_t rows = P.row1 - P.row0;
         P.slot_base = (uint32_t)slots; P.launch_base = (uint32_t)launches;
-        slots += (uint64_t)P.gw * P.gh * P.spp;
-        launches += (uint64_t)P.gw * P.gh;
+        slots += (uint64_t)P.gw * rows * P.spp;
+        launches += (uint64_t)P.gw * rows;
         fd.pass[p] = P;
     }
     if (slots * FOVPT_SHARDS >= (1ull << 32)) return fail(c, FOVPT_E_INVALID, "launch too large: %llu sample slots", (unsigned long long)slots);
@@ -221,7 +265,6 @@ int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passe
     fd.rank = c->cfg.rank; fd.world = c->cfg.world < 1 ? 1 : c->cfg.world;
     fd.tile_w = c->cfg.tile_w > 0 ? c->cfg.tile_w : 8; fd.tile_h = c->cfg.tile_h > 0 ? c->cfg.tile_h : 4;
 
-    c->stats.frames++;
     if (slots == 0) return FOVPT_OK;
     int rc = ensure_state(c, (size_t)slots, (size_t)launches);
     if (rc) return rc;
@@ -312,6 +355,7 @@ int fovpt_create(fovpt_ctx** out, int device)
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
     c->grid = c->num_cus * 8;                 // 8 blocks of 256 = 32 waves per CU, grid-stride over the queues
     c->grid_shadow = c->num_cus * 4;
+    if (const char* sb = getenv("FOVPT_SLOT_BUDGET")) { const long long v = atoll(sb); if (v > 0) c->slot_budget = (uint64_t)v; }   // tests: force chunking
     // the main chain is the critical path: give it the higher priority so occlusion waves only fill gaps
     int prio_lo = 0, prio_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);

@@ -79,6 +79,7 @@ struct PassDev {                  // one optixLaunch worth of parameters
     uint32_t redraw;              // frame.redraw
     uint32_t slot_base;           // first sample slot of this pass
     uint32_t launch_base;         // first launch record of this pass
+    uint32_t row0, row1;          // launch rows [row0, row1) handled by this job (a chunk of a large launch)
     uint32_t pad;
 };
 
@@ -99,6 +100,7 @@ struct FrameDev {
     int32_t max_depth;
     int32_t accumulate;
     int32_t rank, world, tile_w, tile_h;
+    int32_t chunked;              // 1: this job is one of several over the same frame (no zero fill of foreign pixels' holes)
 };
 
 // Per-sample-slot path state (SoA, 16-B vectors so every access is one dwordx4).

@@ -489,6 +489,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, Pat
             s = rel - li * P.spp;
             ly = li / P.gw;
             lx = li - ly * P.gw;
+            ly += P.row0;                                      // slots and launch records are relative to the chunk
             live = ring_alive(fd, P, lx, ly, ix, iy) && launch_owned(fd, p, lx, ly);
         }
         if (live) {
@@ -515,7 +516,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, Pat
             if (s == P.spp - 1) {                                               // backplate of the last sample, :495
                 float u, v;
                 probe_dir_to_uv(dir, u, v);
-                ps.backplate[P.launch_base + ly * P.gw + lx] = probe_eval(fd.probe, fd.probe_row_mul, u, v);
+                ps.backplate[P.launch_base + (ly - P.row0) * P.gw + lx] = probe_eval(fd.probe, fd.probe_row_mul, u, v);
             }
         }
         const uint32_t pos = block_append(cnt->q[0], cap, live, s_scratch);
@@ -1052,13 +1053,15 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_resolve(const FrameDev fd, Path
             long long xa, xb, ya, yb;
             writer_range(x, (uint32_t)fd.w, P.fx, P.fill, P.offx, P.gw, xa, xb);
             writer_range(y, (uint32_t)fd.h, P.fy, P.fill, P.offy, P.gh, ya, yb);
+            if (ya < (long long)P.row0) ya = P.row0;           // only this chunk's launch rows
+            if (yb > (long long)P.row1 - 1) yb = (long long)P.row1 - 1;
             for (long long ly = yb; ly >= ya && state == 0; ly--) {
                 for (long long lx = xb; lx >= xa; lx--) {
                     uint32_t ix, iy;
                     if (!ring_alive(fd, P, (uint32_t)lx, (uint32_t)ly, ix, iy)) continue;
                     state = launch_owned(fd, p, (uint32_t)lx, (uint32_t)ly) ? 1 : 2;
                     wp = p;
-                    wli = (uint32_t)ly * P.gw + (uint32_t)lx;
+                    wli = ((uint32_t)ly - P.row0) * P.gw + (uint32_t)lx;
                     key = P.launch_base + wli;
                     break;
                 }
@@ -1140,7 +1143,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_resolve(const FrameDev fd, Path
             if (fd.g_color) fd.g_color[image_index] = fovpt_float4{a.x, a.y, a.z, 1.0f};
             if (fd.g_albedo) fd.g_albedo[image_index] = fovpt_float4{ga.x, ga.y, ga.z, 1.0f};
         }
-    } else if (state == 2 || (fd.world > 1 && fd.rank != 0)) {
+    } else if (state == 2 || (fd.world > 1 && fd.rank != 0 && !fd.chunked)) {
         // another rank's pixel (or nobody's, on a rank other than 0): zero keeps the sum-gather exact
         fd.accum[image_index] = fovpt_float4{0.f, 0.f, 0.f, 0.f};
         fd.frame[image_index] = 0u;

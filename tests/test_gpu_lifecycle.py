@@ -186,3 +186,32 @@ def test_bench_two_rank_rehearsal_gathers_the_full_frame():
     assert out["n_gpus"] == 2 and out["scaling"] == "strong"
     assert out["gather_mismatch_vs_single_gpu"] == 0
     assert out["config"]["rays_per_frame"] > 3.0e6        # both ranks' rays are counted
+
+
+@pytest.mark.parametrize("uniform", [False, True])
+def test_chunked_jobs_for_large_launches(oracle, monkeypatch, uniform):
+    """Launches whose sample slots exceed the per-job budget (the reference's own 3840x2160 x 32 spp FOV_OFF
+    benchmark has 265 M) are cut into row chunks run in launch order.  Forced here with a tiny budget."""
+    monkeypatch.setenv("FOVPT_SLOT_BUDGET", "3000")
+    size = (160, 96)
+    cfg = cfg_uniform(3, 4) if uniform else cfg_foveated(10, 30, (1, 2, 8))
+    model = scenes.atrium(5000)
+    r = make_gpu(model, scenes.sky_probe(), scenes.ATRIUM_CAMERA, size, cfg)
+    r.render()
+    S, F = make_oracle(oracle, model, scenes.sky_probe(), scenes.ATRIUM_CAMERA, size)
+    cnt = oracle.render(S, F, cfg)
+    assert _eq(r.downloadAccum(), F.accum) and np.array_equal(r.downloadPixels(), F.frame)
+    st = r.stats()
+    assert st.paths == cnt[2] and st.frames == 1
+    r.close()
+    # sharded + chunked: the shards still add up
+    monkeypatch.setenv("FOVPT_SLOT_BUDGET", "5000")
+    total = np.zeros((size[1], size[0]), np.uint64)
+    for rank in range(2):
+        c = cfg.copy()
+        c.rank, c.world = rank, 2
+        rr = make_gpu(model, scenes.sky_probe(), scenes.ATRIUM_CAMERA, size, c)
+        rr.render()
+        total += rr.downloadPixels()
+        rr.close()
+    assert np.array_equal(total.astype(np.uint32), F.frame)
