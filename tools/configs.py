@@ -51,3 +51,9 @@ if "REF" in which:   # the reference's own shipped settings: 74/241, 8/16/32 spp
     c = abi.Config.reference_default(); run("REF-shipped", 262144, (1920, 1080), c)
 if "U4" in which:    # FOV_OFF as shipped: uniform 4 spp
     c = abi.Config.reference_default(); c.uniform = 1; run("FOV_OFF-4spp", 262144, (1920, 1080), c, frames=5)
+if "PUBF" in which:  # the reference's published foveated benchmark: 3840x2160, radii 74/241, spp 32/16/8 (133.7 ms on its RTX GPU, Sponza)
+    c = abi.Config.reference_default(); c.spp_periphery, c.spp_middle, c.spp_fovea = 8, 16, 32
+    run("published-fov-4K-32/16/8", 262144, (3840, 2160), c, frames=5)
+if "PUBU" in which:  # the reference's published uniform benchmark: 3840x2160, 32 spp (3405 ms on its RTX GPU, Sponza)
+    c = abi.Config.reference_default(); c.uniform, c.spp_uniform = 1, 32
+    run("published-uniform-4K-32spp", 262144, (3840, 2160), c, frames=2)
