@@ -260,3 +260,23 @@ def test_full_size_benchmark_configs_against_oracle(oracle, name):
     # r_outer is skipped although its far pixels lie beyond the middle ring (reference behaviour, kept)
     holes = (ga[..., 3] != 1).mean()
     assert holes == 0 if name == "C2" else holes < 0.01
+
+
+def test_bistro_class_scene_full_size_against_oracle(oracle):
+    """BASELINE.json configs[3] geometry on one GPU: ~3.8 M triangles (17-level wide BVH), 2560x1440,
+    foveated 8/2/1 with radii 197/643.  Whole frame bit-exact against the oracle."""
+    W, H = 2560, 1440
+    model = scenes.atrium(3800000, material="app")
+    cfg = cfg_foveated(197, 643, (1, 2, 8))
+    probe = scenes.ambient_probe(W, H, 2.5)
+    r = make_gpu(model, probe, scenes.ATRIUM_CAMERA, (W, H), cfg)
+    r.render()
+    ga, gf = r.downloadAccum(), r.downloadPixels()
+    st = r.stats()
+    r.close()
+    assert st.num_triangles == model.num_triangles and st.bvh_max_depth <= 21
+    S, F = make_oracle(oracle, model, probe, scenes.ATRIUM_CAMERA, (W, H))
+    cnt = oracle.render(S, F, cfg, nthreads=min(32, os.cpu_count() or 1))
+    l2, bits, px = compare_frames(ga, gf, F.accum, F.frame)
+    assert l2 <= 1e-4 and bits == 0 and px == 0, (l2, bits, px)
+    assert st.paths == cnt[2] == 1726659          # SURVEY 8(a): paths per frame of C4
