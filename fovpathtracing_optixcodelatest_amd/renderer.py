@@ -196,6 +196,23 @@ class SampleRenderer:
         cam.U, cam.V, cam.W = U, V, W
         cam.eye.set(self.lastSetCamera.eye())
 
+    def setCameraFov(self, eye, forward, up, angle_left, angle_right, angle_up, angle_down):
+        """Per-eye asymmetric frustum from OpenXR-style half angles (XrFovf, radians; left/down negative), as the
+        VR callers of the path compute them (OtherProjects_01/11HelloRaytracingOpenXR/main.cpp:891-897).  The raygen
+        maps d in [-1,1]^2 to dir = d.x*U + d.y*V + W (deviceProgram.cu:483-491), so an off-centre frustum is W
+        shifted by the tangent-space centre and U, V scaled by the tangent-space half extents."""
+        f = np.array(forward, np.float64)
+        f = f / np.linalg.norm(f)
+        r_ = np.cross(f, np.array(up, np.float64))
+        r_ = r_ / np.linalg.norm(r_)
+        u = np.cross(r_, f)
+        tl, tr, tu, td = (float(np.tan(a)) for a in (angle_left, angle_right, angle_up, angle_down))
+        cam = self.launchParams.camera
+        cam.eye.set(eye)
+        cam.U.set((0.5 * (tr - tl)) * r_)
+        cam.V.set((0.5 * (tu - td)) * u)
+        cam.W.set(f + (0.5 * (tr + tl)) * r_ + (0.5 * (tu + td)) * u)
+
     def setProbe(self, probe: ProbeData):
         """SimplePathtracer.cpp:292-308; raises like CUDAProbeData::createBuffer (Probe.h:104-105)."""
         if not probe.valid:

@@ -215,3 +215,31 @@ def test_chunked_jobs_for_large_launches(oracle, monkeypatch, uniform):
         total += rr.downloadPixels()
         rr.close()
     assert np.array_equal(total.astype(np.uint32), F.frame)
+
+
+def test_stereo_asymmetric_frusta(oracle):
+    """Two eyes = two cameras and two render() calls per frame (BASELINE.json configs[4]); per-eye off-centre
+    frusta enter only through camera U, V, W, so the oracle sees the same LaunchParams."""
+    size = (128, 128)
+    model, probe = scenes.atrium(5000), scenes.sky_probe()
+    cfg = cfg_foveated(10, 30, (1, 2, 4), max_depth=8)
+    r = make_gpu(model, probe, scenes.ATRIUM_CAMERA, size, cfg)
+    S, F = make_oracle(oracle, model, probe, scenes.ATRIUM_CAMERA, size)
+    fwd = np.array(scenes.ATRIUM_CAMERA["lookat"], np.float64) - np.array(scenes.ATRIUM_CAMERA["eye"], np.float64)
+    for eye_dx, (al, ar) in ((-3.2, (-0.9, 0.7)), (3.2, (-0.7, 0.9))):
+        eye = (scenes.ATRIUM_CAMERA["eye"][0], scenes.ATRIUM_CAMERA["eye"][1], scenes.ATRIUM_CAMERA["eye"][2] + eye_dx)
+        r.setCameraFov(eye, fwd, (0, 1, 0), al, ar, 0.8, -0.8)
+        F.lp.camera = r.launchParams.camera
+        for lp in (r.launchParams, F.lp):
+            lp.frame.subframe_index = 0
+        r.render()
+        oracle.render(S, F, cfg)
+        assert _eq(r.downloadAccum(), F.accum)
+    # a symmetric XrFovf equals sutil::Camera::UVWFrame up to rounding
+    r.setCameraFov(scenes.ATRIUM_CAMERA["eye"], fwd, (0, 1, 0), -0.5, 0.5, 0.5, -0.5)
+    a = np.array(r.launchParams.camera.U.tolist() + r.launchParams.camera.V.tolist())
+    r.setCamera(renderer.Camera(scenes.ATRIUM_CAMERA["eye"], scenes.ATRIUM_CAMERA["lookat"], (0, 1, 0), np.degrees(1.0), 1.0))
+    wlen = np.linalg.norm(fwd)
+    b = np.array(r.launchParams.camera.U.tolist() + r.launchParams.camera.V.tolist()) / wlen
+    assert np.allclose(a, b, rtol=1e-4, atol=1e-5)
+    r.close()
