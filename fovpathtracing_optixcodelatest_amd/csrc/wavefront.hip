@@ -26,6 +26,9 @@
 #ifndef FOVPT_V_WAVEAPPEND
 #define FOVPT_V_WAVEAPPEND 0
 #endif
+#ifndef FOVPT_V_UNIPUSH
+#define FOVPT_V_UNIPUSH 1
+#endif
 #ifndef FOVPT_V_STEPSTAT
 #define FOVPT_V_STEPSTAT 0
 #endif
@@ -621,6 +624,88 @@ __device__ inline TriRec load_tri(const TriRec* __restrict__ tris, uint32_t i)
 // One ray per quad.  Everything that steers control flow (cur, sp, the quad-wide best distance) is
 // identical in the four lanes; each lane keeps the best hit among the triangles IT tested and the
 // four are merged once, at the end, by (t, primitive id) -- the same total order as a sequential scan.
+//
+// A node step is issue-bound, so it is kept short: the hit mask of the quad comes out of the wave
+// ballot (one shift), every hit lane stores its child at stack[sp + H-1-rank] and the next node is
+// simply popped -- descending and backtracking are the same code, no cross-lane selects.
+#if FOVPT_V_UNIPUSH
+__device__ inline uint32_t quad_rot1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x39, 0xf, 0xf, true); }   // [1,2,3,0]
+__device__ inline uint32_t quad_rot2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true); }   // [2,3,0,1]
+__device__ inline uint32_t quad_rot3(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x93, 0xf, 0xf, true); }   // [3,0,1,2]
+
+template <bool ANY_HIT>
+__device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __restrict__ stack /* [e * QUADS_PER_BLOCK] */, uint32_t j,
+                                     float& bt, float& bu, float& bv, uint32_t& bpos, uint32_t& bprim, bool& occluded)
+{
+    static_assert(FOVPT_LEAF_MAX <= 4, "a leaf is tested in one quad step");
+    const uint32_t qshift = threadIdx.x & 60u;          // first lane of this quad within its wave
+    const uint32_t below = (1u << j) - 1u;
+    int cur = 0, sp = 0;
+    float lim = TMAX;                                   // closest: prunes boxes beyond the quad-wide best hit
+    for (;;) {
+        // ---- wide internal nodes: lane j owns child j
+        while (cur >= 0) {
+            const float4* np = (const float4*)(sc.nodes + cur) + 2 * j;
+            const float4 a = np[0], b = np[1];
+            const int code = __float_as_int(b.z);
+            float t;
+            const bool h = box_hit(r, a.x, a.y, a.z, a.w, b.x, b.y, TMIN, lim, t);
+            const uint32_t m4 = (uint32_t)(__builtin_amdgcn_ballot_w64(h) >> qshift) & 15u;
+            const int H = __builtin_popcount(m4);
+            int rank;
+            if (ANY_HIT) {
+                rank = __builtin_popcount(m4 & below);              // storage order (distance order was measured slower)
+            } else {
+                // front to back.  The key orders by entry distance (t >= TMIN > 0: the bit pattern is
+                // monotonic) with the lane in the two lowest bits, so keys are distinct; the order of
+                // traversal does not change the result, only the amount of pruning.
+                const uint32_t key = h ? ((__float_as_uint(t) & ~3u) | j) : (0x7f800000u | j);
+                rank = (int)(quad_rot1(key) < key) + (int)(quad_rot2(key) < key) + (int)(quad_rot3(key) < key);
+            }
+            // lanes that missed their child store into the spare row: no branch, and the child code is
+            // needed unconditionally (the compiler would otherwise sink its load below the box test)
+            stack[(h ? sp + H - 1 - rank : FOVPT_STACK) * FOVPT_QUADS_PER_BLOCK] = code;
+            sp += H;
+            __builtin_amdgcn_wave_barrier();
+            if (sp == 0) { cur = TRAV_DONE; break; }
+            cur = stack[--sp * FOVPT_QUADS_PER_BLOCK];
+        }
+        if (cur == TRAV_DONE) return;
+        // ---- leaf: lane j owns triangle j (branch-free: the four lanes of 16 rays never agree on an early out)
+        {
+            const uint32_t lcode = (uint32_t)~cur;
+            const uint32_t first = lcode >> 3, count = (lcode & 7u) + 1u;
+            const uint32_t k = j < count ? j : 0u;
+            const TriRec T = load_tri(sc.tris, first + k);
+            const V3 d = v3(r.dx, r.dy, r.dz);
+            const V3 e1 = v3(T.e1x, T.e1y, T.e1z), e2 = v3(T.e2x, T.e2y, T.e2z);
+            const V3 p = cross(d, e2);
+            const float det = dot(e1, p);
+            const float inv = 1.0f / det;
+            const V3 s = v3(r.ox, r.oy, r.oz) - v3(T.v0x, T.v0y, T.v0z);
+            const float u = dot(s, p) * inv;
+            const V3 q = cross(s, e1);
+            const float v = dot(d, q) * inv;
+            const float t = dot(e2, q) * inv;
+            const bool ok = (j < count) & (det != 0.0f) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > TMIN) & (t < TMAX);
+            if (ANY_HIT) {
+                // front face: counter-clockwise seen from the origin
+                if ((uint32_t)(__builtin_amdgcn_ballot_w64(ok & (det > 0.0f)) >> qshift) & 15u) { occluded = true; return; }
+            } else {
+                const bool better = ok & ((t < bt) | ((t == bt) & (T.prim < bprim)));
+                bt = better ? t : bt; bu = better ? u : bu; bv = better ? v : bv;
+                bpos = better ? first + j : bpos; bprim = better ? T.prim : bprim;
+                lim = fminf(TMAX, quad_min(bt) * 1.000001f);
+            }
+            if (sp == 0) return;
+            cur = stack[--sp * FOVPT_QUADS_PER_BLOCK];
+        }
+    }
+}
+#else
+// (previous formulation) One ray per quad.  Everything that steers control flow (cur, sp, the quad-wide best distance) is
+// identical in the four lanes; each lane keeps the best hit among the triangles IT tested and the
+// four are merged once, at the end, by (t, primitive id) -- the same total order as a sequential scan.
 template <bool ANY_HIT>
 __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __restrict__ stack /* [e * QUADS_PER_BLOCK] */, uint32_t j,
                                      float& bt, float& bu, float& bv, uint32_t& bpos, uint32_t& bprim, bool& occluded)
@@ -694,6 +779,8 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
     }
 }
 
+#endif
+
 // One traversal launch handles the occlusion rays of iteration it_shadow and/or the closest-hit rays of
 // iteration it_closest as one index space [shadow | radiance], one ray per QUAD of lanes, static
 // grid-stride over quads (waves are homogeneous in ray kind: the shadow part is padded to 16 rays).
@@ -702,7 +789,7 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
 __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneView sc, PathState ps, const uint32_t* __restrict__ queue, ShadowQueue sq,
                                                                          uint32_t cap, Counters* __restrict__ cnt, int it_closest, int it_shadow)
 {
-    __shared__ int s_stack[FOVPT_STACK * FOVPT_QUADS_PER_BLOCK];
+    __shared__ int s_stack[(FOVPT_STACK + FOVPT_V_UNIPUSH) * FOVPT_QUADS_PER_BLOCK];      // + the spare row of the unified push
     ShardMap ms, mq;
     ms.load(cnt->sq[it_shadow >= 0 ? it_shadow : 0]);
     mq.load(cnt->q[it_closest >= 0 ? it_closest : 0]);
