@@ -415,7 +415,8 @@ int fovpt_set_scene(fovpt_ctx* c, const fovpt_mesh_desc* meshes, int num_meshes,
         if (D.texture_id >= num_textures) return fail(c, FOVPT_E_INVALID, "mesh %d references texture %d of %d (SimplePathtracer.cpp:581-583 would index out of range)", m, D.texture_id, num_textures);
     }
     if (ntri == 0) return fail(c, FOVPT_E_INVALID, "scene has no triangles");
-    if (ntri >= (1ull << 28)) return fail(c, FOVPT_E_INVALID, "too many triangles");
+    // the traversal addresses 48-B triangle records and 128-B nodes with 32-bit byte offsets
+    if (ntri > (1ull << 26)) return fail(c, FOVPT_E_INVALID, "too many triangles (%llu > 2^26)", (unsigned long long)ntri);
     // flatten on the host: 9 floats per triangle in global primitive order (mesh order, then index order)
     std::vector<float> flat((size_t)ntri * 9);
     std::vector<uint32_t> mesh_of((size_t)ntri);
@@ -486,6 +487,10 @@ int fovpt_set_scene(fovpt_ctx* c, const fovpt_mesh_desc* meshes, int num_meshes,
     if (3 * br.max_depth + 1 > FOVPT_STACK) {       // a wide node leaves at most 3 entries behind
         (void)hipFree(br.nodes); (void)hipFree(br.tris);
         return fail(c, FOVPT_E_BVH_DEPTH, "hierarchy depth %u needs more than the %d traversal stack entries", br.max_depth, FOVPT_STACK);
+    }
+    if (br.node_bytes >= (1ull << 32) || br.tri_bytes >= (1ull << 32)) {
+        (void)hipFree(br.nodes); (void)hipFree(br.tris);
+        return fail(c, FOVPT_E_INVALID, "hierarchy of %llu bytes exceeds the 32-bit offsets of the traversal", (unsigned long long)br.node_bytes);
     }
     c->nodes = br.nodes; c->tris = br.tris;
     c->num_tris = (uint32_t)ntri;

@@ -616,6 +616,17 @@ __device__ inline TriRec load_tri(const TriRec* __restrict__ tris, uint32_t i)
     return T;
 }
 
+__device__ inline TriRec load_tri_off(const TriRec* __restrict__ tris, uint32_t byte_off)
+{
+    const float4* p = (const float4*)((const char*)tris + byte_off);
+    const float4 a = p[0], b = p[1], c = p[2];
+    TriRec T;
+    T.v0x = a.x; T.v0y = a.y; T.v0z = a.z; T.e1x = a.w;
+    T.e1y = b.x; T.e1z = b.y; T.e2x = b.z; T.e2y = b.w;
+    T.e2z = c.x; T.prim = __float_as_uint(c.y); T.mesh = __float_as_uint(c.z); T.pad = 0;
+    return T;
+}
+
 #define TMIN 0.01f     // deviceProgram.cu:41
 #define TMAX 1e16f     // deviceProgram.cu:42
 
@@ -640,35 +651,40 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
     static_assert(FOVPT_LEAF_MAX <= 4, "a leaf is tested in one quad step");
     const uint32_t qshift = threadIdx.x & 60u;          // first lane of this quad within its wave
     const uint32_t below = (1u << j) - 1u;
-    int cur = 0, sp = 0;
+    const uint32_t j32 = 32u * j;
+    // row 0 holds the end marker, so "pop" needs no emptiness test; rows sp.. are free
+    if (j == 0) stack[0] = TRAV_DONE;
+    int cur = 0, sp = 1;
     float lim = TMAX;                                   // closest: prunes boxes beyond the quad-wide best hit
     for (;;) {
         // ---- wide internal nodes: lane j owns child j
         while (cur >= 0) {
-            const float4* np = (const float4*)(sc.nodes + cur) + 2 * j;
+            // uniform base + 32-bit offset (fovpt_set_scene keeps nodes and triangles below 4 GB)
+            const float4* np = (const float4*)((const char*)sc.nodes + (((uint32_t)cur << 7) | j32));
             const float4 a = np[0], b = np[1];
             const int code = __float_as_int(b.z);
             float t;
             const bool h = box_hit(r, a.x, a.y, a.z, a.w, b.x, b.y, TMIN, lim, t);
             const uint32_t m4 = (uint32_t)(__builtin_amdgcn_ballot_w64(h) >> qshift) & 15u;
             const int H = __builtin_popcount(m4);
-            int rank;
+            // Every lane stores its child: the H hits land on rows sp .. sp+H-1 (the one to visit next on
+            // top), the misses on the free rows above them -- no branch, no select on the address.
+            int row;
             if (ANY_HIT) {
-                rank = __builtin_popcount(m4 & below);              // storage order (distance order was measured slower)
+                // storage order (distance order was measured slower)
+                const int hb = __builtin_popcount(m4 & below);
+                row = h ? sp + H - 1 - hb : sp + H + ((int)j - hb);
             } else {
                 // front to back.  The key orders by entry distance (t >= TMIN > 0: the bit pattern is
-                // monotonic) with the lane in the two lowest bits, so keys are distinct; the order of
-                // traversal does not change the result, only the amount of pruning.
-                const uint32_t key = h ? ((__float_as_uint(t) & ~3u) | j) : (0x7f800000u | j);
-                rank = (int)(quad_rot1(key) < key) + (int)(quad_rot2(key) < key) + (int)(quad_rot3(key) < key);
+                // monotonic) with the lane in the two lowest bits, so keys are distinct; misses sort
+                // first.  The visiting order does not change the result, only the amount of pruning.
+                const uint32_t key = ((h ? __float_as_uint(t) : 0u) & ~3u) | j;
+                row = sp + 3 - (int)(quad_rot1(key) < key) - (int)(quad_rot2(key) < key) - (int)(quad_rot3(key) < key);
             }
-            // lanes that missed their child store into the spare row: no branch, and the child code is
-            // needed unconditionally (the compiler would otherwise sink its load below the box test)
-            stack[(h ? sp + H - 1 - rank : FOVPT_STACK) * FOVPT_QUADS_PER_BLOCK] = code;
-            sp += H;
+            stack[row * FOVPT_QUADS_PER_BLOCK] = code;
+            sp += H - 1;
             __builtin_amdgcn_wave_barrier();
-            if (sp == 0) { cur = TRAV_DONE; break; }
-            cur = stack[--sp * FOVPT_QUADS_PER_BLOCK];
+            cur = stack[sp * FOVPT_QUADS_PER_BLOCK];
         }
         if (cur == TRAV_DONE) return;
         // ---- leaf: lane j owns triangle j (branch-free: the four lanes of 16 rays never agree on an early out)
@@ -676,7 +692,7 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
             const uint32_t lcode = (uint32_t)~cur;
             const uint32_t first = lcode >> 3, count = (lcode & 7u) + 1u;
             const uint32_t k = j < count ? j : 0u;
-            const TriRec T = load_tri(sc.tris, first + k);
+            const TriRec T = load_tri_off(sc.tris, ((first + k) * 3u) << 4);          // 48-B records
             const V3 d = v3(r.dx, r.dy, r.dz);
             const V3 e1 = v3(T.e1x, T.e1y, T.e1z), e2 = v3(T.e2x, T.e2y, T.e2z);
             const V3 p = cross(d, e2);
@@ -697,7 +713,6 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
                 bpos = better ? first + j : bpos; bprim = better ? T.prim : bprim;
                 lim = fminf(TMAX, quad_min(bt) * 1.000001f);
             }
-            if (sp == 0) return;
             cur = stack[--sp * FOVPT_QUADS_PER_BLOCK];
         }
     }
@@ -789,7 +804,7 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
 __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneView sc, PathState ps, const uint32_t* __restrict__ queue, ShadowQueue sq,
                                                                          uint32_t cap, Counters* __restrict__ cnt, int it_closest, int it_shadow)
 {
-    __shared__ int s_stack[(FOVPT_STACK + FOVPT_V_UNIPUSH) * FOVPT_QUADS_PER_BLOCK];      // + the spare row of the unified push
+    __shared__ int s_stack[(FOVPT_STACK + 4 * FOVPT_V_UNIPUSH) * FOVPT_QUADS_PER_BLOCK];  // + the end marker and three rows of slack above the top
     ShardMap ms, mq;
     ms.load(cnt->sq[it_shadow >= 0 ? it_shadow : 0]);
     mq.load(cnt->q[it_closest >= 0 ? it_closest : 0]);
