@@ -26,9 +26,6 @@
 #ifndef FOVPT_V_WAVEAPPEND
 #define FOVPT_V_WAVEAPPEND 0
 #endif
-#ifndef FOVPT_V_UNIPUSH
-#define FOVPT_V_UNIPUSH 1
-#endif
 #ifndef FOVPT_V_STEPSTAT
 #define FOVPT_V_STEPSTAT 0
 #endif
@@ -574,7 +571,8 @@ __device__ inline void ray_setup(RayT& r, const float4& o, const float4& d)
     r.ix = safe_rcp(d.x); r.iy = safe_rcp(d.y); r.iz = safe_rcp(d.z);
     r.nox = -o.x * r.ix; r.noy = -o.y * r.iy; r.noz = -o.z * r.iz;
 }
-// conservative slab test (boxes are padded at build time); returns entry distance in tn
+// conservative slab test (boxes are padded at build time); returns entry distance in tn.
+// (Six scalar fmas: the v_pk_fma_f32 form on (lo, hi) pairs was measured 12 % slower.)
 __device__ inline bool box_hit(const RayT& r, float lx, float ly, float lz, float hx, float hy, float hz, float tmin, float tmax, float& tn)
 {
     const float ax = __builtin_fmaf(lx, r.ix, r.nox), bx = __builtin_fmaf(hx, r.ix, r.nox);
@@ -639,7 +637,6 @@ __device__ inline TriRec load_tri_off(const TriRec* __restrict__ tris, uint32_t 
 // A node step is issue-bound, so it is kept short: the hit mask of the quad comes out of the wave
 // ballot (one shift), every hit lane stores its child at stack[sp + H-1-rank] and the next node is
 // simply popped -- descending and backtracking are the same code, no cross-lane selects.
-#if FOVPT_V_UNIPUSH
 __device__ inline uint32_t quad_rot1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x39, 0xf, 0xf, true); }   // [1,2,3,0]
 __device__ inline uint32_t quad_rot2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true); }   // [2,3,0,1]
 __device__ inline uint32_t quad_rot3(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x93, 0xf, 0xf, true); }   // [3,0,1,2]
@@ -649,12 +646,18 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
                                      float& bt, float& bu, float& bv, uint32_t& bpos, uint32_t& bprim, bool& occluded)
 {
     static_assert(FOVPT_LEAF_MAX <= 4, "a leaf is tested in one quad step");
+    static_assert(FOVPT_QUADS_PER_BLOCK == 64, "row stride of the stack is 256 bytes");
     const uint32_t qshift = threadIdx.x & 60u;          // first lane of this quad within its wave
     const uint32_t below = (1u << j) - 1u;
     const uint32_t j32 = 32u * j;
-    // row 0 holds the end marker, so "pop" needs no emptiness test; rows sp.. are free
+    // Row 0 holds the end marker, so "pop" needs no emptiness test.  `top` is the byte address of the
+    // first free row (rows are FOVPT_QUADS_PER_BLOCK ints apart); all row arithmetic stays in bytes.
+    enum { ROWB = FOVPT_QUADS_PER_BLOCK * 4 };
+    const uint32_t from_me = 15u & ~below;              // lanes j..3 of the quad
+    const int miss_rows = (int)(j + 1u) * ROWB;
     if (j == 0) stack[0] = TRAV_DONE;
-    int cur = 0, sp = 1;
+    char* top = (char*)stack + ROWB;
+    int cur = 0;
     float lim = TMAX;                                   // closest: prunes boxes beyond the quad-wide best hit
     for (;;) {
         // ---- wide internal nodes: lane j owns child j
@@ -666,25 +669,27 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
             float t;
             const bool h = box_hit(r, a.x, a.y, a.z, a.w, b.x, b.y, TMIN, lim, t);
             const uint32_t m4 = (uint32_t)(__builtin_amdgcn_ballot_w64(h) >> qshift) & 15u;
-            const int H = __builtin_popcount(m4);
-            // Every lane stores its child: the H hits land on rows sp .. sp+H-1 (the one to visit next on
-            // top), the misses on the free rows above them -- no branch, no select on the address.
-            int row;
+            int Hm1;                                    // H - 1 in one instruction (the compiler splits popcount - 1)
+            asm("v_bcnt_u32_b32 %0, %1, -1" : "=v"(Hm1) : "v"(m4));
+            // Every lane stores its child: the H hits land on rows top .. top+H-1 (the one to visit next
+            // last), the misses on the free rows above them -- no branch, no select on the address.
+            int row;                                    // in bytes, relative to top
             if (ANY_HIT) {
                 // storage order (distance order was measured slower)
-                const int hb = __builtin_popcount(m4 & below);
-                row = h ? sp + H - 1 - hb : sp + H + ((int)j - hb);
+                row = ((__builtin_popcount(m4 & from_me) - 1) << 8) + (h ? 0 : miss_rows);
             } else {
                 // front to back.  The key orders by entry distance (t >= TMIN > 0: the bit pattern is
-                // monotonic) with the lane in the two lowest bits, so keys are distinct; misses sort
-                // first.  The visiting order does not change the result, only the amount of pruning.
+                // monotonic) with the lane in the two lowest bits, so keys are distinct and below 2^31
+                // (the sign of a difference is the comparison); misses sort first.  The visiting order
+                // does not change the result, only the amount of pruning.
                 const uint32_t key = ((h ? __float_as_uint(t) : 0u) & ~3u) | j;
-                row = sp + 3 - (int)(quad_rot1(key) < key) - (int)(quad_rot2(key) < key) - (int)(quad_rot3(key) < key);
+                const int lt = ((int)(quad_rot1(key) - key) >> 31) + ((int)(quad_rot2(key) - key) >> 31) + ((int)(quad_rot3(key) - key) >> 31);
+                row = (lt << 8) + 3 * ROWB;             // 3 - (number of keys below mine)
             }
-            stack[row * FOVPT_QUADS_PER_BLOCK] = code;
-            sp += H - 1;
+            *(int*)(top + row) = code;
+            top += Hm1 * ROWB;                          // H pushed, one popped
             __builtin_amdgcn_wave_barrier();
-            cur = stack[sp * FOVPT_QUADS_PER_BLOCK];
+            cur = *(const int*)top;
         }
         if (cur == TRAV_DONE) return;
         // ---- leaf: lane j owns triangle j (branch-free: the four lanes of 16 rays never agree on an early out)
@@ -713,88 +718,11 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
                 bpos = better ? first + j : bpos; bprim = better ? T.prim : bprim;
                 lim = fminf(TMAX, quad_min(bt) * 1.000001f);
             }
-            cur = stack[--sp * FOVPT_QUADS_PER_BLOCK];
+            top -= ROWB;
+            cur = *(const int*)top;
         }
     }
 }
-#else
-// (previous formulation) One ray per quad.  Everything that steers control flow (cur, sp, the quad-wide best distance) is
-// identical in the four lanes; each lane keeps the best hit among the triangles IT tested and the
-// four are merged once, at the end, by (t, primitive id) -- the same total order as a sequential scan.
-template <bool ANY_HIT>
-__device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __restrict__ stack /* [e * QUADS_PER_BLOCK] */, uint32_t j,
-                                     float& bt, float& bu, float& bv, uint32_t& bpos, uint32_t& bprim, bool& occluded)
-{
-    int cur = 0, sp = 0;
-    float btq = INFINITY;              // min over the quad of bt: prunes boxes
-    for (;;) {
-        // ---- wide internal nodes: lane j owns child j
-        while (cur >= 0) {
-            const float4* np = (const float4*)(sc.nodes + cur) + 2 * j;
-            const float4 a = np[0], b = np[1];
-            const int code = __float_as_int(b.z);
-            const float lim = ANY_HIT ? TMAX : fminf(TMAX, btq * 1.000001f);
-            float t;
-            const bool h = box_hit(r, a.x, a.y, a.z, a.w, b.x, b.y, TMIN, lim, t);
-            const float tk = h ? t : INFINITY;
-            const float t0 = quad_bcast<0>(tk), t1 = quad_bcast<1>(tk), t2 = quad_bcast<2>(tk), t3 = quad_bcast<3>(tk);
-            const int c0 = quad_bcast<0>(code), c1 = quad_bcast<1>(code), c2 = quad_bcast<2>(code), c3 = quad_bcast<3>(code);
-            const bool h0 = t0 < INFINITY, h1 = t1 < INFINITY, h2 = t2 < INFINITY, h3 = t3 < INFINITY;
-            const int H = (int)h0 + (int)h1 + (int)h2 + (int)h3;
-            if (H == 0) {
-                if (sp == 0) { cur = TRAV_DONE; break; }
-                cur = stack[--sp * FOVPT_QUADS_PER_BLOCK];
-                continue;
-            }
-            int rank, next;
-            if (ANY_HIT) {
-                // any order will do: storage order (sorting by distance was measured slower)
-                rank = (j > 0 && h0) + (j > 1 && h1) + (j > 2 && h2);
-                next = h0 ? c0 : (h1 ? c1 : (h2 ? c2 : c3));
-            } else {
-                // front to back: rank by (entry distance, child index)
-                rank = (int)(t0 < tk || (t0 == tk && j > 0)) + (int)(t1 < tk || (t1 == tk && j > 1))
-                     + (int)(t2 < tk || (t2 == tk && j > 2)) + (int)(t3 < tk);
-                // (for j == k the term is false by construction: t_k < t_k is false and j > k is false)
-                float tm = t0; next = c0;
-                if (t1 < tm) { tm = t1; next = c1; }
-                if (t2 < tm) { tm = t2; next = c2; }
-                if (t3 < tm) { tm = t3; next = c3; }
-            }
-            // the H-1 other hits go onto the stack in one step, farthest deepest
-            if (h && rank >= 1) stack[(sp + H - 1 - rank) * FOVPT_QUADS_PER_BLOCK] = code;
-            sp += H - 1;
-            cur = next;
-        }
-        if (cur == TRAV_DONE) return;
-        // ---- leaf: lane j owns triangle j
-        {
-            const uint32_t lcode = (uint32_t)~cur;
-            const uint32_t first = lcode >> 3, count = (lcode & 7u) + 1u;
-            int occ = 0;
-            for (uint32_t k = j; k < count; k += 4) {
-                const TriRec T = load_tri(sc.tris, first + k);
-                float t, u, v, det;
-                if (!tri_hit(r, T, t, u, v, det)) continue;
-                if (!(t > TMIN && t < TMAX)) continue;
-                if (ANY_HIT) {
-                    if (det > 0.0f) occ = 1;                          // front face: counter-clockwise seen from the origin
-                } else if (t < bt || (t == bt && T.prim < bprim)) {
-                    bt = t; bu = u; bv = v; bpos = first + k; bprim = T.prim;
-                }
-            }
-            if (ANY_HIT) {
-                if (quad_or(occ)) { occluded = true; return; }
-            } else {
-                btq = quad_min(bt);
-            }
-            if (sp == 0) return;
-            cur = stack[--sp * FOVPT_QUADS_PER_BLOCK];
-        }
-    }
-}
-
-#endif
 
 // One traversal launch handles the occlusion rays of iteration it_shadow and/or the closest-hit rays of
 // iteration it_closest as one index space [shadow | radiance], one ray per QUAD of lanes, static
@@ -804,7 +732,7 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
 __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneView sc, PathState ps, const uint32_t* __restrict__ queue, ShadowQueue sq,
                                                                          uint32_t cap, Counters* __restrict__ cnt, int it_closest, int it_shadow)
 {
-    __shared__ int s_stack[(FOVPT_STACK + 4 * FOVPT_V_UNIPUSH) * FOVPT_QUADS_PER_BLOCK];  // + the end marker and three rows of slack above the top
+    __shared__ int s_stack[(FOVPT_STACK + 4) * FOVPT_QUADS_PER_BLOCK];  // + the end marker and three rows of slack above the top
     ShardMap ms, mq;
     ms.load(cnt->sq[it_shadow >= 0 ? it_shadow : 0]);
     mq.load(cnt->q[it_closest >= 0 ? it_closest : 0]);

@@ -5,7 +5,7 @@ NAME=$1; shift
 cd /root/repo/fovpathtracing_optixcodelatest_amd/csrc
 mkdir -p /tmp/v_$NAME /root/repo/build
 for f in fovpt_api wavefront bvh_build; do
-  hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fPIC -std=c++17 "$@" -c $f.hip -o /tmp/v_$NAME/$f.o &
+  hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fPIC -std=c++17 "$@" -c $f.hip -o /tmp/v_$NAME/$f.o &
 done
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o /root/repo/build/libfovpt_$NAME.so /tmp/v_$NAME/*.o
