@@ -173,7 +173,8 @@ __global__ void k_refit(const Box* __restrict__ boxes, const uint32_t* __restric
     }
 }
 
-__device__ inline int leaf_code(int first, int count) { return ~((first << 3) | (count - 1)); }
+// leaf: ~((first triangle's offset in 16-byte units) << 3 | (count - 1)); a TriRec is three such units
+__device__ inline int leaf_code(int first, int count) { return ~(((first * 3) << 3) | (count - 1)); }
 
 __global__ void k_iota(uint32_t* v, uint32_t n)
 {

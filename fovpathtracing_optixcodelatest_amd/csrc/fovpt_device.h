@@ -33,7 +33,7 @@ static_assert(sizeof(TriRec) == 48, "TriRec");
 // 4-wide BVH node: four 32-byte child records.  The traversal gives one ray to four adjacent lanes
 // (a quad); lane j of the quad owns child j and fetches exactly its record (two 16-byte loads, the
 // quad's eight loads cover the 128-byte node).  code >= 0: index of a wide node; code < 0: leaf,
-// ~code = (first_tri << 3) | (count-1).  An unused slot holds the degenerate box lo = hi = +inf,
+// ~code = (offset of the first triangle in 16-byte units << 3) | (count-1).  An unused slot holds the degenerate box lo = hi = +inf,
 // which no ray passes.
 struct alignas(16) BvhChild {
     float lox, loy, loz, hix;

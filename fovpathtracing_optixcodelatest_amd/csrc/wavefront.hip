@@ -579,7 +579,10 @@ __device__ inline bool box_hit(const RayT& r, float lx, float ly, float lz, floa
     const float ay = __builtin_fmaf(ly, r.iy, r.noy), by = __builtin_fmaf(hy, r.iy, r.noy);
     const float az = __builtin_fmaf(lz, r.iz, r.noz), bz = __builtin_fmaf(hz, r.iz, r.noz);
     const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-    const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    // tmax > 0: as signed integers the bit patterns order like the values whenever one is positive,
+    // so the clamp is one v_min_i32 (no canonicalisation of the loop-carried tmax)
+    const float far = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const float t1 = __int_as_float(min(__float_as_int(far), __float_as_int(tmax)));
     tn = t0;
     return t0 <= t1 * 1.0000004f;
 }
@@ -649,7 +652,7 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
     static_assert(FOVPT_QUADS_PER_BLOCK == 64, "row stride of the stack is 256 bytes");
     const uint32_t qshift = threadIdx.x & 60u;          // first lane of this quad within its wave
     const uint32_t below = (1u << j) - 1u;
-    const uint32_t j32 = 32u * j;
+    const uint32_t j32 = 32u * j, j3 = 3u * j;
     // Row 0 holds the end marker, so "pop" needs no emptiness test.  `top` is the byte address of the
     // first free row (rows are FOVPT_QUADS_PER_BLOCK ints apart); all row arithmetic stays in bytes.
     enum { ROWB = FOVPT_QUADS_PER_BLOCK * 4 };
@@ -682,7 +685,8 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
                 // monotonic) with the lane in the two lowest bits, so keys are distinct and below 2^31
                 // (the sign of a difference is the comparison); misses sort first.  The visiting order
                 // does not change the result, only the amount of pruning.
-                const uint32_t key = ((h ? __float_as_uint(t) : 0u) & ~3u) | j;
+                uint32_t key;
+                asm("v_and_or_b32 %0, %1, -4, %2" : "=v"(key) : "v"(h ? __float_as_uint(t) : 0u), "v"(j));
                 const int lt = ((int)(quad_rot1(key) - key) >> 31) + ((int)(quad_rot2(key) - key) >> 31) + ((int)(quad_rot3(key) - key) >> 31);
                 row = (lt << 8) + 3 * ROWB;             // 3 - (number of keys below mine)
             }
@@ -692,12 +696,12 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
             cur = *(const int*)top;
         }
         if (cur == TRAV_DONE) return;
-        // ---- leaf: lane j owns triangle j (branch-free: the four lanes of 16 rays never agree on an early out)
+        // ---- leaf: lane j owns triangle j (branch-free: the four lanes of 16 rays never agree on an early out).
+        // A lane beyond the leaf's count repeats triangle 0: the duplicate candidate changes nothing.
         {
             const uint32_t lcode = (uint32_t)~cur;
-            const uint32_t first = lcode >> 3, count = (lcode & 7u) + 1u;
-            const uint32_t k = j < count ? j : 0u;
-            const TriRec T = load_tri_off(sc.tris, ((first + k) * 3u) << 4);          // 48-B records
+            const uint32_t tri16 = (lcode >> 3) + (j <= (lcode & 7u) ? j3 : 0u);     // in 16-byte units
+            const TriRec T = load_tri_off(sc.tris, tri16 << 4);
             const V3 d = v3(r.dx, r.dy, r.dz);
             const V3 e1 = v3(T.e1x, T.e1y, T.e1z), e2 = v3(T.e2x, T.e2y, T.e2z);
             const V3 p = cross(d, e2);
@@ -708,15 +712,21 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
             const V3 q = cross(s, e1);
             const float v = dot(d, q) * inv;
             const float t = dot(e2, q) * inv;
-            const bool ok = (j < count) & (det != 0.0f) & (u >= 0.0f) & (u <= 1.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > TMIN) & (t < TMAX);
+            // the contract's tests; "det != 0" and "u <= 1" are implied: with det == 0 u is +-inf or NaN
+            // and then u >= 0 or u + v <= 1 fails; v >= 0 and fl(u + v) <= 1 give u <= 1
+            const bool ok = (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > TMIN) & (t < TMAX);
             if (ANY_HIT) {
                 // front face: counter-clockwise seen from the origin
                 if ((uint32_t)(__builtin_amdgcn_ballot_w64(ok & (det > 0.0f)) >> qshift) & 15u) { occluded = true; return; }
             } else {
                 const bool better = ok & ((t < bt) | ((t == bt) & (T.prim < bprim)));
                 bt = better ? t : bt; bu = better ? u : bu; bv = better ? v : bv;
-                bpos = better ? first + j : bpos; bprim = better ? T.prim : bprim;
-                lim = fminf(TMAX, quad_min(bt) * 1.000001f);
+                bpos = better ? tri16 : bpos; bprim = better ? T.prim : bprim;
+                // quad-wide best: bt > 0 or +inf, so the bit patterns order like the values
+                uint32_t m = __float_as_uint(bt);
+                m = min(m, quad_rot2(m));
+                m = min(m, quad_rot1(m));
+                lim = fminf(TMAX, __uint_as_float(m) * 1.000001f);
             }
             top -= ROWB;
             cur = *(const int*)top;
@@ -847,7 +857,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
             } else {
                 const float4 o4 = ps.ray_o[slot], d4 = ps.ray_d[slot];
                 const V3 ray_o = v3(o4), ray_dir = v3(d4);
-                const TriRec T = load_tri(sc.tris, tpos);
+                const TriRec T = load_tri_off(sc.tris, tpos << 4);            // tpos: offset in 16-byte units
                 const MeshDev M = sc.meshes[T.mesh];
                 const Mat& mat = M.material;
                 const V3 e1 = v3(T.e1x, T.e1y, T.e1z), e2 = v3(T.e2x, T.e2y, T.e2z);
