@@ -134,6 +134,9 @@ struct Counters {       // device-resident, zeroed per frame except the stats bl
     uint32_t q[FOVPT_MAX_ITERS + 1][FOVPT_SHARDS];    // radiance queue sizes per iteration (q[0] = camera rays)
     uint32_t sq[FOVPT_MAX_ITERS + 1][FOVPT_SHARDS];   // shadow queue sizes per iteration
     unsigned long long stat_radiance, stat_shadow, stat_paths;
+    // diagnostics of a -DFOVPT_V_STEPSTAT=1 build (tools/stepstat.py): per ray kind [closest, any-hit]
+    // wave-level node steps, active quads in them, wave-level leaf steps, active quads in them
+    unsigned long long diag[2][4];
 };
 
 // ---- launchers implemented in wavefront.hip / bvh_build.hip -------------------------------

@@ -646,7 +646,7 @@ __device__ inline uint32_t quad_rot3(uint32_t v) { return (uint32_t)__builtin_am
 
 template <bool ANY_HIT>
 __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __restrict__ stack /* [e * QUADS_PER_BLOCK] */, uint32_t j,
-                                     float& bt, float& bu, float& bv, uint32_t& bpos, uint32_t& bprim, bool& occluded)
+                                     float& bt, float& bu, float& bv, uint32_t& bpos, uint32_t& bprim, bool& occluded, unsigned long long* diag)
 {
     static_assert(FOVPT_LEAF_MAX <= 4, "a leaf is tested in one quad step");
     static_assert(FOVPT_QUADS_PER_BLOCK == 64, "row stride of the stack is 256 bytes");
@@ -665,6 +665,12 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
     for (;;) {
         // ---- wide internal nodes: lane j owns child j
         while (cur >= 0) {
+#if FOVPT_V_STEPSTAT
+            {
+                const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
+                if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ex)) { atomicAdd(diag + 0, 1ull); atomicAdd(diag + 1, (unsigned long long)(__builtin_popcountll(ex) >> 2)); }
+            }
+#endif
             // uniform base + 32-bit offset (fovpt_set_scene keeps nodes and triangles below 4 GB)
             const float4* np = (const float4*)((const char*)sc.nodes + (((uint32_t)cur << 7) | j32));
             const float4 a = np[0], b = np[1];
@@ -699,6 +705,12 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
         // ---- leaf: lane j owns triangle j (branch-free: the four lanes of 16 rays never agree on an early out).
         // A lane beyond the leaf's count repeats triangle 0: the duplicate candidate changes nothing.
         {
+#if FOVPT_V_STEPSTAT
+            {
+                const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
+                if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ex)) { atomicAdd(diag + 2, 1ull); atomicAdd(diag + 3, (unsigned long long)(__builtin_popcountll(ex) >> 2)); }
+            }
+#endif
             const uint32_t lcode = (uint32_t)~cur;
             const uint32_t tri16 = (lcode >> 3) + (j <= (lcode & 7u) ? j3 : 0u);     // in 16-byte units
             const TriRec T = load_tri_off(sc.tris, tri16 << 4);
@@ -768,7 +780,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
             float bt = INFINITY, bu = 0.f, bv = 0.f;
             uint32_t bpos = 0, bprim = 0;
             bool occ = false;
-            traverse_quad<true>(sc, r, stack, j, bt, bu, bv, bpos, bprim, occ);
+            traverse_quad<true>(sc, r, stack, j, bt, bu, bv, bpos, bprim, occ, cnt->diag[1]);
             if (j == 0) {
                 // the deferred NEE add of SampleLights / SampleShadow (deviceProgram.cu:323-341,367-385).
                 // Every (slot, depth) cell has exactly one writer, so this is a plain store and the shadow
@@ -786,7 +798,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
             float bt = INFINITY, bu = 0.f, bv = 0.f;
             uint32_t bpos = 0xffffffffu, bprim = 0xffffffffu;
             bool occ = false;
-            traverse_quad<false>(sc, r, stack, j, bt, bu, bv, bpos, bprim, occ);
+            traverse_quad<false>(sc, r, stack, j, bt, bu, bv, bpos, bprim, occ, cnt->diag[0]);
             // merge the four lanes' candidates: lowest t, then lowest primitive id, then lowest lane
             const float t0 = quad_bcast<0>(bt), t1 = quad_bcast<1>(bt), t2 = quad_bcast<2>(bt), t3 = quad_bcast<3>(bt);
             const int p0 = quad_bcast<0>((int)bprim), p1 = quad_bcast<1>((int)bprim), p2 = quad_bcast<2>((int)bprim), p3 = quad_bcast<3>((int)bprim);

@@ -1,4 +1,6 @@
-"""Diagnostic: per-shadow-ray traversal step histogram of the last bounce (needs a -DFOVPT_V_STEPSTAT=1 build)."""
+"""Diagnostic: SIMD utilisation of the traversal kernel (needs a -DFOVPT_V_STEPSTAT=1 build, FOVPT_SO=...).
+
+Per ray kind: wave-level node / leaf steps, and how many of the 16 rays of a wave take part in each."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,29 +15,17 @@ cfg = abi.Config.reference_default(); cfg.r_inner, cfg.r_outer = 148, 482
 cfg.spp_periphery, cfg.spp_middle, cfg.spp_fovea = 1, 2, 8
 r.config = cfg
 r.launchParams.frame.c.x, r.launchParams.frame.c.y = W // 2, H // 2
+r.reset_stats()
 r.render()
+st = r.stats()
 L = lib.load()
-def buf(name, dtype):
-    p, n = C.c_void_p(), C.c_size_t()
-    lib.check(r._ctx, L.fovpt_debug_buffer(r._ctx, name.encode(), C.byref(p), C.byref(n)))
-    a = np.empty(n.value // np.dtype(dtype).itemsize, dtype)
-    r.download(p.value, a)
-    return a
-cnt = buf("counters", np.uint32)
-sq_counts = cnt[64 * 8:64 * 8 + 64 * 8].reshape(64, 8)
-print("shadow queue sizes per iteration:", sq_counts[:4].sum(1))
-occ = buf("sq_occ", np.float32).reshape(-1, 4)
-vis = buf("sq_vis", np.float32).reshape(-1, 4)
-cap = occ.shape[0] // 8
-steps, isocc = [], []
-for s in range(8):
-    n = sq_counts[3][s]
-    st = occ[s * cap:s * cap + n, 3].view(np.uint32)
-    steps.append(st); isocc.append(vis[s * cap:s * cap + n, 3])
-steps = np.concatenate(steps); isocc = np.concatenate(isocc)
-nodes, leaves = steps & 0xFFFF, steps >> 16
-print("last bounce shadow rays:", steps.size, "occluded fraction %.3f" % isocc.mean())
-for name, v in (("node visits", nodes), ("leaf visits", leaves)):
-    print(name, "mean %.1f median %d p90 %d p99 %d max %d" % (v.mean(), np.median(v), np.percentile(v, 90), np.percentile(v, 99), v.max()))
-for lab, m in (("occluded", isocc > 0.5), ("visible", isocc < 0.5)):
-    print(lab, "n", m.sum(), "nodes mean %.1f max %d  leaves mean %.1f max %d" % (nodes[m].mean(), nodes[m].max(), leaves[m].mean(), leaves[m].max()))
+p, n = C.c_void_p(), C.c_size_t()
+lib.check(r._ctx, L.fovpt_debug_buffer(r._ctx, b"counters", C.byref(p), C.byref(n)))
+raw = np.empty(n.value, np.uint8)
+r.download(p.value, raw)
+diag = raw[4096 + 24:4096 + 24 + 64].view(np.uint64).reshape(2, 4)
+rays = {"closest": st.radiance_rays, "any-hit": st.shadow_rays}
+for k, name in enumerate(("closest", "any-hit")):
+    ns, nq, ls, lq = (int(x) for x in diag[k])
+    print("%-8s rays %9d | node: wave steps %10d, rays/step %5.2f of 16, steps/ray %5.1f | leaf: wave steps %9d, rays/step %5.2f, steps/ray %4.1f"
+          % (name, rays[name], ns, nq / max(ns, 1), nq / max(rays[name], 1), ls, lq / max(ls, 1), lq / max(rays[name], 1)))
