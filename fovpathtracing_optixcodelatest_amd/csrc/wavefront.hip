@@ -452,6 +452,21 @@ struct ShardMap {
         if (i >= p7) { s = 7; base = p7; }
         return s * cap + (i - base);
     }
+    // the same for lane index i of 16 consecutive indices starting at the wave-uniform i0: the shard is
+    // found with scalar instructions unless the 16 straddle a shard boundary
+    __device__ inline uint32_t phys16(uint32_t i, uint32_t i0, uint32_t cap) const
+    {
+        uint32_t s = 0, base = 0, next = p1;
+        if (i0 >= p1) { s = 1; base = p1; next = p2; }
+        if (i0 >= p2) { s = 2; base = p2; next = p3; }
+        if (i0 >= p3) { s = 3; base = p3; next = p4; }
+        if (i0 >= p4) { s = 4; base = p4; next = p5; }
+        if (i0 >= p5) { s = 5; base = p5; next = p6; }
+        if (i0 >= p6) { s = 6; base = p6; next = p7; }
+        if (i0 >= p7) { s = 7; base = p7; next = 0xffffffffu; }
+        if (i0 + 15u < next) return s * cap - base + i;
+        return phys(i, cap);
+    }
 };
 
 __device__ inline bool launch_owned(const FrameDev& fd, int p, uint32_t lx, uint32_t ly)
@@ -562,8 +577,10 @@ struct RayT {
 
 __device__ inline float safe_rcp(float d)
 {
+    // v_rcp_f32 (1 ulp) is enough: the reciprocal only feeds the conservative box test, whose boxes are
+    // padded by >= 1e-5 of the coordinate magnitude at build time (bvh_build.hip, k_tri_bounds)
     const float a = fabsf(d) < 1e-20f ? copysignf(1e-20f, d) : d;
-    return 1.0f / a;
+    return __builtin_amdgcn_rcpf(a);
 }
 __device__ inline void ray_setup(RayT& r, const float4& o, const float4& d)
 {
@@ -771,9 +788,10 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
     int* stack = s_stack + (threadIdx.x >> 2);
     const uint32_t quads = gridDim.x * FOVPT_QUADS_PER_BLOCK;
     for (uint32_t i = blockIdx.x * FOVPT_QUADS_PER_BLOCK + (threadIdx.x >> 2); i < n_total; i += quads) {
+        const uint32_t i0 = __builtin_amdgcn_readfirstlane(i - ((threadIdx.x & 63u) >> 2));      // the wave's 16 rays: i0 .. i0+15
         if (i < n_sh_pad) {
             if (i >= n_sh) continue;
-            const uint32_t ph = ms.phys(i, cap);
+            const uint32_t ph = ms.phys16(i, i0, cap);
             const float4 o = sq.o[ph], d = sq.d[ph];
             RayT r;
             ray_setup(r, o, d);
@@ -792,21 +810,24 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
                 *cell = make_float4(val.x, val.y, val.z, 0.f);
             }
         } else {
-            const uint32_t slot = queue[mq.phys(i - n_sh_pad, cap)];
+            const uint32_t slot = queue[mq.phys16(i - n_sh_pad, i0 - n_sh_pad, cap)];
             RayT r;
             ray_setup(r, ps.ray_o[slot], ps.ray_d[slot]);
             float bt = INFINITY, bu = 0.f, bv = 0.f;
             uint32_t bpos = 0xffffffffu, bprim = 0xffffffffu;
             bool occ = false;
             traverse_quad<false>(sc, r, stack, j, bt, bu, bv, bpos, bprim, occ, cnt->diag[0]);
-            // merge the four lanes' candidates: lowest t, then lowest primitive id, then lowest lane
-            const float t0 = quad_bcast<0>(bt), t1 = quad_bcast<1>(bt), t2 = quad_bcast<2>(bt), t3 = quad_bcast<3>(bt);
-            const int p0 = quad_bcast<0>((int)bprim), p1 = quad_bcast<1>((int)bprim), p2 = quad_bcast<2>((int)bprim), p3 = quad_bcast<3>((int)bprim);
-            uint32_t w = 0; float tw = t0; uint32_t pw = (uint32_t)p0;
-            if (t1 < tw || (t1 == tw && (uint32_t)p1 < pw)) { w = 1; tw = t1; pw = (uint32_t)p1; }
-            if (t2 < tw || (t2 == tw && (uint32_t)p2 < pw)) { w = 2; tw = t2; pw = (uint32_t)p2; }
-            if (t3 < tw || (t3 == tw && (uint32_t)p3 < pw)) { w = 3; tw = t3; pw = (uint32_t)p3; }
-            if (j == w) ps.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(bpos));
+            // merge the four lanes' candidates: lowest t (bit patterns of t > 0 order like the values),
+            // then lowest primitive id.  Lanes that tie on both hold the same triangle, hence the same
+            // record: they all store it.
+            uint32_t mt = __float_as_uint(bt);
+            mt = min(mt, quad_rot2(mt));
+            mt = min(mt, quad_rot1(mt));
+            const bool cand = __float_as_uint(bt) == mt;
+            uint32_t mp = cand ? bprim : 0xffffffffu;
+            mp = min(mp, quad_rot2(mp));
+            mp = min(mp, quad_rot1(mp));
+            if (cand && bprim == mp) ps.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(bpos));
         }
     }
 }
