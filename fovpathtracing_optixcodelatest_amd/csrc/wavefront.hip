@@ -661,113 +661,216 @@ __device__ inline uint32_t quad_rot1(uint32_t v) { return (uint32_t)__builtin_am
 __device__ inline uint32_t quad_rot2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true); }   // [2,3,0,1]
 __device__ inline uint32_t quad_rot3(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x93, 0xf, 0xf, true); }   // [3,0,1,2]
 
-template <bool ANY_HIT>
-__device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __restrict__ stack /* [e * QUADS_PER_BLOCK] */, uint32_t j,
-                                     float& bt, float& bu, float& bv, uint32_t& bpos, uint32_t& bprim, bool& occluded, unsigned long long* diag)
+enum { ROWB = FOVPT_QUADS_PER_BLOCK * 4 };      // byte distance of two stack rows
+static_assert(FOVPT_LEAF_MAX <= 4, "a leaf is tested in one quad step");
+static_assert(FOVPT_QUADS_PER_BLOCK == 64, "row stride of the stack is 256 bytes");
+
+struct QuadLane {                                   // per-lane constants of the quad traversal
+    uint32_t j, qshift, from_me, j32, j3;
+    int miss_rows;
+    __device__ inline void init()
+    {
+        j = threadIdx.x & 3u;
+        qshift = threadIdx.x & 60u;                 // first lane of this quad within its wave
+        from_me = 15u & ~((1u << j) - 1u);          // lanes j..3 of the quad
+        j32 = 32u * j; j3 = 3u * j;
+        miss_rows = (int)(j + 1u) * ROWB;
+    }
+};
+struct QuadTrav {                                   // state of one ray's traversal (identical in the 4 lanes except the best hit)
+    int cur;                                        // node >= 0, leaf < 0, TRAV_DONE
+    char* top;                                      // byte address of the first free stack row
+    float lim;                                      // closest: prunes boxes beyond the quad-wide best hit
+    float bt, bu, bv; uint32_t bpos, bprim;         // best hit among the triangles THIS lane tested
+    // Row 0 holds the end marker, so "pop" needs no emptiness test; all row arithmetic stays in bytes.
+    __device__ inline void start(int* stack, const QuadLane& q)
+    {
+        if (q.j == 0) stack[0] = TRAV_DONE;
+        top = (char*)stack + ROWB;
+        cur = 0; lim = TMAX;
+        bt = INFINITY; bu = 0.f; bv = 0.f; bpos = 0xffffffffu; bprim = 0xffffffffu;
+    }
+};
+
+#if FOVPT_V_STEPSTAT
+__device__ inline void stepstat(unsigned long long* diag)
 {
-    static_assert(FOVPT_LEAF_MAX <= 4, "a leaf is tested in one quad step");
-    static_assert(FOVPT_QUADS_PER_BLOCK == 64, "row stride of the stack is 256 bytes");
-    const uint32_t qshift = threadIdx.x & 60u;          // first lane of this quad within its wave
-    const uint32_t below = (1u << j) - 1u;
-    const uint32_t j32 = 32u * j, j3 = 3u * j;
-    // Row 0 holds the end marker, so "pop" needs no emptiness test.  `top` is the byte address of the
-    // first free row (rows are FOVPT_QUADS_PER_BLOCK ints apart); all row arithmetic stays in bytes.
-    enum { ROWB = FOVPT_QUADS_PER_BLOCK * 4 };
-    const uint32_t from_me = 15u & ~below;              // lanes j..3 of the quad
-    const int miss_rows = (int)(j + 1u) * ROWB;
-    if (j == 0) stack[0] = TRAV_DONE;
-    char* top = (char*)stack + ROWB;
-    int cur = 0;
-    float lim = TMAX;                                   // closest: prunes boxes beyond the quad-wide best hit
+    const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
+    if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ex)) { atomicAdd(diag + 0, 1ull); atomicAdd(diag + 1, (unsigned long long)(__builtin_popcountll(ex) >> 2)); }
+}
+#define STEPSTAT(d) stepstat(d)
+#else
+#define STEPSTAT(d)
+#endif
+
+// wide internal node: lane j owns child j
+template <bool ANY_HIT>
+__device__ inline void node_step(const SceneView& sc, const RayT& r, const QuadLane& q, QuadTrav& T)
+{
+    // uniform base + 32-bit offset (fovpt_set_scene keeps nodes and triangles below 4 GB)
+    const float4* np = (const float4*)((const char*)sc.nodes + (((uint32_t)T.cur << 7) | q.j32));
+    const float4 a = np[0], b = np[1];
+    const int code = __float_as_int(b.z);
+    float t;
+    const bool h = box_hit(r, a.x, a.y, a.z, a.w, b.x, b.y, TMIN, T.lim, t);
+    const uint32_t m4 = (uint32_t)(__builtin_amdgcn_ballot_w64(h) >> q.qshift) & 15u;
+    int Hm1;                                    // H - 1 in one instruction (the compiler splits popcount - 1)
+    asm("v_bcnt_u32_b32 %0, %1, -1" : "=v"(Hm1) : "v"(m4));
+    // Every lane stores its child: the H hits land on rows top .. top+H-1 (the one to visit next
+    // last), the misses on the free rows above them -- no branch, no select on the address.
+    int row;                                    // in bytes, relative to top
+    if (ANY_HIT) {
+        // storage order (distance order was measured slower)
+        row = ((__builtin_popcount(m4 & q.from_me) - 1) << 8) + (h ? 0 : q.miss_rows);
+    } else {
+        // front to back.  The key orders by entry distance (t >= TMIN > 0: the bit pattern is
+        // monotonic) with the lane in the two lowest bits, so keys are distinct and below 2^31
+        // (the sign of a difference is the comparison); misses sort first.  The visiting order
+        // does not change the result, only the amount of pruning.
+        uint32_t key;
+        asm("v_and_or_b32 %0, %1, -4, %2" : "=v"(key) : "v"(h ? __float_as_uint(t) : 0u), "v"(q.j));
+        const int lt = ((int)(quad_rot1(key) - key) >> 31) + ((int)(quad_rot2(key) - key) >> 31) + ((int)(quad_rot3(key) - key) >> 31);
+        row = (lt << 8) + 3 * ROWB;             // 3 - (number of keys below mine)
+    }
+    *(int*)(T.top + row) = code;
+    T.top += Hm1 * ROWB;                        // H pushed, one popped
+    __builtin_amdgcn_wave_barrier();
+    T.cur = *(const int*)T.top;
+}
+
+// leaf: lane j owns triangle j (branch-free: the four lanes of 16 rays never agree on an early out).
+// A lane beyond the leaf's count repeats triangle 0: the duplicate candidate changes nothing.
+// Any-hit: returns true when a front-facing triangle was hit (the ray is occluded, nothing is popped).
+template <bool ANY_HIT>
+__device__ inline bool leaf_step(const SceneView& sc, const RayT& r, const QuadLane& q, QuadTrav& T)
+{
+    const uint32_t lcode = (uint32_t)~T.cur;
+    const uint32_t tri16 = (lcode >> 3) + (q.j <= (lcode & 7u) ? q.j3 : 0u);     // in 16-byte units
+    const TriRec R = load_tri_off(sc.tris, tri16 << 4);
+    const V3 d = v3(r.dx, r.dy, r.dz);
+    const V3 e1 = v3(R.e1x, R.e1y, R.e1z), e2 = v3(R.e2x, R.e2y, R.e2z);
+    const V3 p = cross(d, e2);
+    const float det = dot(e1, p);
+    const float inv = 1.0f / det;
+    const V3 s = v3(r.ox, r.oy, r.oz) - v3(R.v0x, R.v0y, R.v0z);
+    const float u = dot(s, p) * inv;
+    const V3 qq = cross(s, e1);
+    const float v = dot(d, qq) * inv;
+    const float t = dot(e2, qq) * inv;
+    // the contract's tests; "det != 0" and "u <= 1" are implied: with det == 0 u is +-inf or NaN
+    // and then u >= 0 or u + v <= 1 fails; v >= 0 and fl(u + v) <= 1 give u <= 1
+    const bool ok = (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > TMIN) & (t < TMAX);
+    if (ANY_HIT) {
+        // front face: counter-clockwise seen from the origin
+        if ((uint32_t)(__builtin_amdgcn_ballot_w64(ok & (det > 0.0f)) >> q.qshift) & 15u) return true;
+    } else {
+        const bool better = ok & ((t < T.bt) | ((t == T.bt) & (R.prim < T.bprim)));
+        T.bt = better ? t : T.bt; T.bu = better ? u : T.bu; T.bv = better ? v : T.bv;
+        T.bpos = better ? tri16 : T.bpos; T.bprim = better ? R.prim : T.bprim;
+        // quad-wide best: bt > 0 or +inf, so the bit patterns order like the values
+        uint32_t m = __float_as_uint(T.bt);
+        m = min(m, quad_rot2(m));
+        m = min(m, quad_rot1(m));
+        T.lim = fminf(TMAX, __uint_as_float(m) * 1.000001f);
+    }
+    T.top -= ROWB;
+    T.cur = *(const int*)T.top;
+    return false;
+}
+
+// closest: store the hit record of the quad's ray.  Lowest t (bit patterns of t > 0 order like the
+// values), then lowest primitive id; lanes that tie on both hold the same triangle, hence the same
+// record: they all store it.
+__device__ inline void store_hit(const PathState& ps, uint32_t slot, const QuadTrav& T)
+{
+    uint32_t mt = __float_as_uint(T.bt);
+    mt = min(mt, quad_rot2(mt));
+    mt = min(mt, quad_rot1(mt));
+    const bool cand = __float_as_uint(T.bt) == mt;
+    uint32_t mp = cand ? T.bprim : 0xffffffffu;
+    mp = min(mp, quad_rot2(mp));
+    mp = min(mp, quad_rot1(mp));
+    if (cand && T.bprim == mp) ps.hit[slot] = make_float4(T.bt, T.bu, T.bv, __uint_as_float(T.bpos));
+}
+// any-hit: the deferred NEE add of SampleLights / SampleShadow (deviceProgram.cu:323-341,367-385).
+// Every (slot, depth) cell has exactly one writer, so this is a plain store and the shadow rays of a
+// bounce may run at any time before resolve (own stream, see fovpt_api.hip)
+__device__ inline void store_shadow(const PathState& ps, const ShadowQueue& sq, uint32_t ph, uint32_t slot, uint32_t target, bool occluded)
+{
+    const float4 val = occluded ? sq.val_occ[ph] : sq.val_vis[ph];
+    float4* cell = target == 0xffffffffu ? ps.alpha + slot : ps.rad + ((size_t)slot * ps.stride + target);
+    *cell = make_float4(val.x, val.y, val.z, 0.f);
+}
+
+// One ray per quad.  Everything that steers control flow (cur, top, the quad-wide best distance) is
+// identical in the four lanes; each lane keeps the best hit among the triangles IT tested and the
+// four are merged once, at the end, by (t, primitive id) -- the same total order as a sequential scan.
+//
+// A node step is issue-bound, so it is kept short: the hit mask of the quad comes out of the wave
+// ballot (one shift), every lane stores its child at a row derived from its rank and the next node is
+// simply popped -- descending and backtracking are the same code, no cross-lane selects.
+__device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __restrict__ stack /* [e * QUADS_PER_BLOCK] */, const QuadLane& q,
+                              QuadTrav& T, unsigned long long* diag)
+{
+    T.start(stack, q);
     for (;;) {
-        // ---- wide internal nodes: lane j owns child j
-        while (cur >= 0) {
-#if FOVPT_V_STEPSTAT
-            {
-                const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
-                if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ex)) { atomicAdd(diag + 0, 1ull); atomicAdd(diag + 1, (unsigned long long)(__builtin_popcountll(ex) >> 2)); }
+        while (T.cur >= 0) { STEPSTAT(diag); node_step<false>(sc, r, q, T); }
+        if (T.cur == TRAV_DONE) return;
+        STEPSTAT(diag + 2);
+        leaf_step<false>(sc, r, q, T);
+    }
+}
+
+// Any-hit traversal over a POOL of shadow rays [first, end) owned by one wave: a quad that has finished
+// its ray takes the next one of the pool as soon as FOVPT_REFILL quads of the wave are idle (all of them
+// at the end), so the wave does not wait for its longest ray after every 16 -- occlusion rays end after
+// very different numbers of steps (SIMD utilisation 36 % with static rounds).  The pool is private to
+// the wave: no atomics.  (For closest-hit rays the same scheme was measured 14 % slower: a refill stalls
+// the whole wave behind two dependent loads, queue -> slot -> ray.)
+#define FOVPT_REFILL 6
+__device__ inline void traverse_shadow_pool(const SceneView& sc, const PathState& ps, const ShadowQueue& sq, const ShardMap& map, uint32_t cap,
+                                            uint32_t first, uint32_t end, int* __restrict__ stack, const QuadLane& q, unsigned long long* diag)
+{
+    QuadTrav T;
+    T.start(stack, q);
+    T.cur = TRAV_DONE;
+    RayT r = {};
+    uint32_t ph = 0;                              // physical index of the quad's shadow record
+    bool pending = false, occluded = false;
+    uint32_t next = first;
+    for (;;) {
+        const unsigned long long idle = __builtin_amdgcn_ballot_w64(T.cur == TRAV_DONE);
+        const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle) >> 2;
+        if (n_idle == 16u || (n_idle >= (uint32_t)FOVPT_REFILL && next < end)) {
+            if (T.cur == TRAV_DONE) {
+                if (pending && q.j == 0) store_shadow(ps, sq, ph, __float_as_uint(sq.o[ph].w), __float_as_uint(sq.d[ph].w), occluded);
+                pending = false;
+                // idle quads below mine (all four lanes of an idle quad are set in the mask)
+                const uint32_t rank = (__builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u)) - q.j) >> 2;
+                const uint32_t idx = next + rank;
+                if (idx < end) {
+                    ph = map.phys16(idx, next, cap);
+                    ray_setup(r, sq.o[ph], sq.d[ph]);
+                    T.start(stack, q);
+                    pending = true; occluded = false;
+                }
             }
-#endif
-            // uniform base + 32-bit offset (fovpt_set_scene keeps nodes and triangles below 4 GB)
-            const float4* np = (const float4*)((const char*)sc.nodes + (((uint32_t)cur << 7) | j32));
-            const float4 a = np[0], b = np[1];
-            const int code = __float_as_int(b.z);
-            float t;
-            const bool h = box_hit(r, a.x, a.y, a.z, a.w, b.x, b.y, TMIN, lim, t);
-            const uint32_t m4 = (uint32_t)(__builtin_amdgcn_ballot_w64(h) >> qshift) & 15u;
-            int Hm1;                                    // H - 1 in one instruction (the compiler splits popcount - 1)
-            asm("v_bcnt_u32_b32 %0, %1, -1" : "=v"(Hm1) : "v"(m4));
-            // Every lane stores its child: the H hits land on rows top .. top+H-1 (the one to visit next
-            // last), the misses on the free rows above them -- no branch, no select on the address.
-            int row;                                    // in bytes, relative to top
-            if (ANY_HIT) {
-                // storage order (distance order was measured slower)
-                row = ((__builtin_popcount(m4 & from_me) - 1) << 8) + (h ? 0 : miss_rows);
-            } else {
-                // front to back.  The key orders by entry distance (t >= TMIN > 0: the bit pattern is
-                // monotonic) with the lane in the two lowest bits, so keys are distinct and below 2^31
-                // (the sign of a difference is the comparison); misses sort first.  The visiting order
-                // does not change the result, only the amount of pruning.
-                uint32_t key;
-                asm("v_and_or_b32 %0, %1, -4, %2" : "=v"(key) : "v"(h ? __float_as_uint(t) : 0u), "v"(j));
-                const int lt = ((int)(quad_rot1(key) - key) >> 31) + ((int)(quad_rot2(key) - key) >> 31) + ((int)(quad_rot3(key) - key) >> 31);
-                row = (lt << 8) + 3 * ROWB;             // 3 - (number of keys below mine)
-            }
-            *(int*)(top + row) = code;
-            top += Hm1 * ROWB;                          // H pushed, one popped
-            __builtin_amdgcn_wave_barrier();
-            cur = *(const int*)top;
+            next = min(end, next + n_idle);
+            if (n_idle == 16u && __builtin_amdgcn_ballot_w64(T.cur != TRAV_DONE) == 0ull) return;      // pool exhausted, all results stored
         }
-        if (cur == TRAV_DONE) return;
-        // ---- leaf: lane j owns triangle j (branch-free: the four lanes of 16 rays never agree on an early out).
-        // A lane beyond the leaf's count repeats triangle 0: the duplicate candidate changes nothing.
-        {
-#if FOVPT_V_STEPSTAT
-            {
-                const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
-                if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ex)) { atomicAdd(diag + 2, 1ull); atomicAdd(diag + 3, (unsigned long long)(__builtin_popcountll(ex) >> 2)); }
-            }
-#endif
-            const uint32_t lcode = (uint32_t)~cur;
-            const uint32_t tri16 = (lcode >> 3) + (j <= (lcode & 7u) ? j3 : 0u);     // in 16-byte units
-            const TriRec T = load_tri_off(sc.tris, tri16 << 4);
-            const V3 d = v3(r.dx, r.dy, r.dz);
-            const V3 e1 = v3(T.e1x, T.e1y, T.e1z), e2 = v3(T.e2x, T.e2y, T.e2z);
-            const V3 p = cross(d, e2);
-            const float det = dot(e1, p);
-            const float inv = 1.0f / det;
-            const V3 s = v3(r.ox, r.oy, r.oz) - v3(T.v0x, T.v0y, T.v0z);
-            const float u = dot(s, p) * inv;
-            const V3 q = cross(s, e1);
-            const float v = dot(d, q) * inv;
-            const float t = dot(e2, q) * inv;
-            // the contract's tests; "det != 0" and "u <= 1" are implied: with det == 0 u is +-inf or NaN
-            // and then u >= 0 or u + v <= 1 fails; v >= 0 and fl(u + v) <= 1 give u <= 1
-            const bool ok = (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > TMIN) & (t < TMAX);
-            if (ANY_HIT) {
-                // front face: counter-clockwise seen from the origin
-                if ((uint32_t)(__builtin_amdgcn_ballot_w64(ok & (det > 0.0f)) >> qshift) & 15u) { occluded = true; return; }
-            } else {
-                const bool better = ok & ((t < bt) | ((t == bt) & (T.prim < bprim)));
-                bt = better ? t : bt; bu = better ? u : bu; bv = better ? v : bv;
-                bpos = better ? tri16 : bpos; bprim = better ? T.prim : bprim;
-                // quad-wide best: bt > 0 or +inf, so the bit patterns order like the values
-                uint32_t m = __float_as_uint(bt);
-                m = min(m, quad_rot2(m));
-                m = min(m, quad_rot1(m));
-                lim = fminf(TMAX, __uint_as_float(m) * 1.000001f);
-            }
-            top -= ROWB;
-            cur = *(const int*)top;
+        while (T.cur >= 0) { STEPSTAT(diag); node_step<true>(sc, r, q, T); }
+        if (T.cur != TRAV_DONE) {
+            STEPSTAT(diag + 2);
+            if (leaf_step<true>(sc, r, q, T)) { occluded = true; T.cur = TRAV_DONE; }
         }
     }
 }
 
+
 // One traversal launch handles the occlusion rays of iteration it_shadow and/or the closest-hit rays of
-// iteration it_closest as one index space [shadow | radiance], one ray per QUAD of lanes, static
-// grid-stride over quads (waves are homogeneous in ray kind: the shadow part is padded to 16 rays).
-// (Dynamic work fetching with per-lane replacement was measured and rejected: with so few rays per
-// resident lane per launch a returning atomic per wave costs more than the imbalance it removes.)
+// iteration it_closest, one ray per QUAD of lanes (16 rays per wave).
+// (Dynamic work fetching with a global counter and per-lane replacement was measured and rejected: with
+// so few rays per resident lane per launch a returning atomic per wave costs more than the imbalance.)
 __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneView sc, PathState ps, const uint32_t* __restrict__ queue, ShadowQueue sq,
                                                                          uint32_t cap, Counters* __restrict__ cnt, int it_closest, int it_shadow)
 {
@@ -777,58 +880,30 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
     mq.load(cnt->q[it_closest >= 0 ? it_closest : 0]);
     const uint32_t n_sh = it_shadow >= 0 ? ms.total() : 0u;
     const uint32_t n_cl = it_closest >= 0 ? mq.total() : 0u;
-    const uint32_t n_sh_pad = (n_sh + 15u) & ~15u;                 // 16 rays per wave
-    const uint32_t n_total = n_sh_pad + n_cl;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (n_cl) atomicAdd(&cnt->stat_radiance, (unsigned long long)n_cl);
         if (n_sh) atomicAdd(&cnt->stat_shadow, (unsigned long long)n_sh);
         if (it_closest == 0) atomicAdd(&cnt->stat_paths, (unsigned long long)n_cl);
     }
-    const uint32_t j = threadIdx.x & 3u;
+    QuadLane q;
+    q.init();
     int* stack = s_stack + (threadIdx.x >> 2);
+    // occlusion rays: every wave owns one contiguous pool
+    if (n_sh) {
+        const uint32_t nwaves = gridDim.x * (FOVPT_BLOCK / 64), wave = blockIdx.x * (FOVPT_BLOCK / 64) + (threadIdx.x >> 6);
+        const uint32_t per = (n_sh + nwaves - 1u) / nwaves, first = min(n_sh, wave * per);
+        traverse_shadow_pool(sc, ps, sq, ms, cap, first, min(n_sh, first + per), stack, q, cnt->diag[1]);
+    }
+    // closest-hit rays: static grid-stride over quads, 16 consecutive rays per wave and round
     const uint32_t quads = gridDim.x * FOVPT_QUADS_PER_BLOCK;
-    for (uint32_t i = blockIdx.x * FOVPT_QUADS_PER_BLOCK + (threadIdx.x >> 2); i < n_total; i += quads) {
+    for (uint32_t i = blockIdx.x * FOVPT_QUADS_PER_BLOCK + (threadIdx.x >> 2); i < n_cl; i += quads) {
         const uint32_t i0 = __builtin_amdgcn_readfirstlane(i - ((threadIdx.x & 63u) >> 2));      // the wave's 16 rays: i0 .. i0+15
-        if (i < n_sh_pad) {
-            if (i >= n_sh) continue;
-            const uint32_t ph = ms.phys16(i, i0, cap);
-            const float4 o = sq.o[ph], d = sq.d[ph];
-            RayT r;
-            ray_setup(r, o, d);
-            float bt = INFINITY, bu = 0.f, bv = 0.f;
-            uint32_t bpos = 0, bprim = 0;
-            bool occ = false;
-            traverse_quad<true>(sc, r, stack, j, bt, bu, bv, bpos, bprim, occ, cnt->diag[1]);
-            if (j == 0) {
-                // the deferred NEE add of SampleLights / SampleShadow (deviceProgram.cu:323-341,367-385).
-                // Every (slot, depth) cell has exactly one writer, so this is a plain store and the shadow
-                // rays of a bounce may run at any time before resolve (own stream, see fovpt_api.hip)
-                const float4 val = occ ? sq.val_occ[ph] : sq.val_vis[ph];
-                const uint32_t slot = __float_as_uint(o.w);
-                const uint32_t target = __float_as_uint(d.w);
-                float4* cell = target == 0xffffffffu ? ps.alpha + slot : ps.rad + ((size_t)slot * ps.stride + target);
-                *cell = make_float4(val.x, val.y, val.z, 0.f);
-            }
-        } else {
-            const uint32_t slot = queue[mq.phys16(i - n_sh_pad, i0 - n_sh_pad, cap)];
-            RayT r;
-            ray_setup(r, ps.ray_o[slot], ps.ray_d[slot]);
-            float bt = INFINITY, bu = 0.f, bv = 0.f;
-            uint32_t bpos = 0xffffffffu, bprim = 0xffffffffu;
-            bool occ = false;
-            traverse_quad<false>(sc, r, stack, j, bt, bu, bv, bpos, bprim, occ, cnt->diag[0]);
-            // merge the four lanes' candidates: lowest t (bit patterns of t > 0 order like the values),
-            // then lowest primitive id.  Lanes that tie on both hold the same triangle, hence the same
-            // record: they all store it.
-            uint32_t mt = __float_as_uint(bt);
-            mt = min(mt, quad_rot2(mt));
-            mt = min(mt, quad_rot1(mt));
-            const bool cand = __float_as_uint(bt) == mt;
-            uint32_t mp = cand ? bprim : 0xffffffffu;
-            mp = min(mp, quad_rot2(mp));
-            mp = min(mp, quad_rot1(mp));
-            if (cand && bprim == mp) ps.hit[slot] = make_float4(bt, bu, bv, __uint_as_float(bpos));
-        }
+        RayT r;
+        QuadTrav T;
+        const uint32_t slot = queue[mq.phys16(i, i0, cap)];
+        ray_setup(r, ps.ray_o[slot], ps.ray_d[slot]);
+        traverse_quad(sc, r, stack, q, T, cnt->diag[0]);
+        store_hit(ps, slot, T);
     }
 }
 
