@@ -522,11 +522,10 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, Pat
             const V3 dir = normalize(dx * U + dy * V + W);                      // :491
             ps.ray_o[slot] = make_float4(fd.eye[0], fd.eye[1], fd.eye[2], 0.f);
             ps.ray_d[slot] = f4(dir, 0.f);
-            ps.thr[slot] = make_float4(1.f, 1.f, 1.f, 1.0f);                    // pathThroughput, rayEta
             ps.rng[slot] = make_uint4(rng.s1, rng.s2, 0u, 0u);                  // stateFlags 0, depth 0
-            for (int dd = 0; dd < fd.max_depth; dd++)                          // directLight / indirectLight terms, :450-451
-                ps.rad[(size_t)slot * ps.stride + dd] = make_float4(0.f, 0.f, 0.f, 0.f);
-            ps.alpha[slot] = make_float4(0.f, 0.f, 0.f, 0.f);
+            // Nothing else is initialised: pathThroughput / rayEta are (1,1,1) / 1 until the first shaded hit
+            // (k_shade), the radiance cells [0, depth) and alpha are written exactly once before resolve
+            // reads them (depth and FLAG_ALPHA_SET tell it which), :450-451
             if (ps.guide_n) { ps.guide_n[slot] = make_float4(0.f, 0.f, 0.f, 0.f); ps.guide_a[slot] = make_float4(0.f, 0.f, 0.f, 0.f); }
             if (s == P.spp - 1) {                                               // backplate of the last sample, :495
                 float u, v;
@@ -934,6 +933,7 @@ __device__ inline float4 tex2d(const TexDev& T, float u, float v)
 }
 
 #define FLAG_ALPHA_ONE 4u      // prd.alpha = make_float3(1) happened (deviceProgram.cu:689)
+#define FLAG_ALPHA_SET 8u      // prd.alpha += ... happened on a shadow catcher (:693): ps.alpha[slot] holds it
 
 #ifndef FOVPT_V_SHADEWAVES
 #define FOVPT_V_SHADEWAVES 1
@@ -985,7 +985,8 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
                     // depth (SECONDARY is set), so this is a plain hit whose one lasting effect is :689
                     flags |= FLAG_ALPHA_ONE | FLAG_DONE;
                 } else {
-                    float4 t4 = ps.thr[slot];
+                    // pathThroughput (1,1,1) and rayEta 1 until the first shaded hit (:447-449)
+                    const float4 t4 = (flags & FLAG_SECONDARY) ? ps.thr[slot] : make_float4(1.f, 1.f, 1.f, 1.0f);
                     V3 thr = v3(t4);
                     float rayEta = t4.w;
                     Rng rng; rng.s1 = rs.x; rng.s2 = rs.y;
@@ -1049,6 +1050,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
                     if (catcher) {
                         // alpha += thr * shadowSample happens regardless of what follows (:693); alpha is still
                         // (0,0,0) here because only a primary hit gets this far on a catcher
+                        flags |= FLAG_ALPHA_SET;
                         if (same) ps.alpha[slot] = f4(v3(0.f) + alpha_occ, 0.f);
                         else {
                             want_shadow = true;
@@ -1246,13 +1248,16 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_resolve(const FrameDev fd, Path
             const uint32_t slot = s0 + s;
             if (ps.guide_n) { gnorm = gnorm + v3(ps.guide_n[slot]); galb = galb + v3(ps.guide_a[slot]); }   // :510-511
             const float4* cells = ps.rad + (size_t)slot * ps.stride;                 // one 16*D-byte record per slot
-            const V3 direct = v3(0.0f) + v3(cells[0]);                                // :523
+            // the path's `depth` segments counted, cell dd holds prd.radiance of segment dd; the reference
+            // adds nothing for a segment it never reached
+            const uint32_t st = ps.rng[slot].z;
+            const int nseg = min((int)(st >> 8), fd.max_depth);
+            const V3 direct = v3(0.0f) + (nseg > 0 ? v3(cells[0]) : v3(0.0f));          // :523
             V3 indirect = v3(0.0f);
-            for (int dd = 1; dd < fd.max_depth; dd++)                                  // :526, in bounce order
+            for (int dd = 1; dd < nseg; dd++)                                          // :526, in bounce order
                 indirect = indirect + v3(cells[dd]);
             result = result + (direct + indirect);
-            const bool one = (ps.rng[slot].z & FLAG_ALPHA_ONE) != 0u;
-            alpha = alpha + (one ? v3(1.0f) : v3(ps.alpha[slot]));
+            alpha = alpha + ((st & FLAG_ALPHA_ONE) ? v3(1.0f) : (st & FLAG_ALPHA_SET) ? v3(ps.alpha[slot]) : v3(0.0f));
         }
         const float sppf = (float)P.spp;
         { const float inv = 1.0f / sppf; alpha = alpha * inv; gnorm = gnorm * inv; galb = galb * inv; }   // :541-543
