@@ -744,9 +744,9 @@ int fovpt_get_stats(fovpt_ctx* c, fovpt_stats* out)
     HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
     drain_events(c);
     if (c->counters.p) {
-        Counters h;
-        HIPCHK(c, hipMemcpy(&h, c->counters.p, sizeof(h), hipMemcpyDeviceToHost));
-        c->stats.radiance_rays = h.stat_radiance; c->stats.shadow_rays = h.stat_shadow; c->stats.paths = h.stat_paths;
+        unsigned long long h[3];                          // stat_radiance, stat_shadow, stat_paths
+        HIPCHK(c, hipMemcpy(h, (const char*)c->counters.p + offsetof(Counters, stat_radiance), sizeof(h), hipMemcpyDeviceToHost));
+        c->stats.radiance_rays = h[0]; c->stats.shadow_rays = h[1]; c->stats.paths = h[2];
     }
     *out = c->stats;
     return FOVPT_OK;

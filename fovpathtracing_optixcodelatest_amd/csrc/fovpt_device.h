@@ -130,14 +130,23 @@ struct ShadowQueue {
 // Queues are sharded: shard s of a queue with capacity `cap` lives at [s*cap, s*cap + count[s]).
 // One returning atomic on ONE word saturates at ~88/us on MI355X, so every producer block appends
 // to the counter of shard blockIdx % 8 with one atomic per block-iteration.
+// Queue sizes live per SHARD, each shard's block FOVPT_SHARD_STRIDE words away from the next: the blocks
+// of one XCD append to one shard, and returning atomics on words of the same memory channel serialise
+// (~88 per microsecond), so the eight shards must not share one.
+#ifndef FOVPT_SHARD_STRIDE
+#define FOVPT_SHARD_STRIDE 128    // uint32 words: 512 B (measured: 0.940 ms/frame; 4 KB: 0.957; all eight in one line: 0.977)
+#endif
 struct Counters {       // device-resident, zeroed per frame except the stats block
-    uint32_t q[FOVPT_MAX_ITERS + 1][FOVPT_SHARDS];    // radiance queue sizes per iteration (q[0] = camera rays)
-    uint32_t sq[FOVPT_MAX_ITERS + 1][FOVPT_SHARDS];   // shadow queue sizes per iteration
+    uint32_t shard[FOVPT_SHARDS][FOVPT_SHARD_STRIDE];   // [s][it]: radiance queue size of iteration it (0 = camera rays);
+                                                        // [s][FOVPT_MAX_ITERS + 1 + it]: shadow queue size
     unsigned long long stat_radiance, stat_shadow, stat_paths;
     // diagnostics of a -DFOVPT_V_STEPSTAT=1 build (tools/stepstat.py): per ray kind [closest, any-hit]
     // wave-level node steps, active quads in them, wave-level leaf steps, active quads in them
     unsigned long long diag[2][4];
 };
+static_assert(2 * (FOVPT_MAX_ITERS + 1) <= FOVPT_SHARD_STRIDE, "shard block holds both queues' sizes");
+#define FOVPT_CNT_Q(it) (it)                               // word index inside a shard's block
+#define FOVPT_CNT_SQ(it) (FOVPT_MAX_ITERS + 1 + (it))
 
 // ---- launchers implemented in wavefront.hip / bvh_build.hip -------------------------------
 struct BvhBuildResult {

@@ -382,7 +382,7 @@ __device__ V3 bsdf_eval(const Mat& mat, const V3& albedo, float etaI, float etaO
 // Ballot compaction into a sharded queue.  Lanes with pred get distinct positions inside shard
 // blockIdx % 8: wave ballot + popcount prefix, the four wave totals meet in LDS, and ONE atomic per
 // block-iteration reserves the range.  Must be called by all 256 threads of the block (two barriers).
-__device__ inline uint32_t block_append(uint32_t* shard_counters, uint32_t cap, bool pred, uint32_t* s_scratch /* [6] */)
+__device__ inline uint32_t block_append(Counters* cnt, int word, uint32_t cap, bool pred, uint32_t* s_scratch /* [6] */)
 {
     const unsigned long long mask = __ballot(pred);
     const uint32_t lane = __lane_id();
@@ -394,7 +394,7 @@ __device__ inline uint32_t block_append(uint32_t* shard_counters, uint32_t cap, 
     const uint32_t shard = blockIdx.x & (FOVPT_SHARDS - 1);
     if (threadIdx.x == 0) {
         const uint32_t total = c0 + c1 + c2 + c3;
-        s_scratch[4] = total ? atomicAdd(&shard_counters[shard], total) : 0u;
+        s_scratch[4] = total ? atomicAdd(&cnt->shard[shard][word], total) : 0u;
     }
     __syncthreads();
     const uint32_t before = (wave > 0 ? c0 : 0u) + (wave > 1 ? c1 : 0u) + (wave > 2 ? c2 : 0u);
@@ -404,7 +404,7 @@ __device__ inline uint32_t block_append(uint32_t* shard_counters, uint32_t cap, 
 }
 
 // Two appends at once (shadow queue and next radiance queue) behind ONE pair of barriers.
-__device__ inline void block_append2(uint32_t* counters_a, bool pred_a, uint32_t* counters_b, bool pred_b, uint32_t cap,
+__device__ inline void block_append2(Counters* cnt, int word_a, bool pred_a, int word_b, bool pred_b, uint32_t cap,
                                      uint32_t* s_scratch /* [10] */, uint32_t& pos_a, uint32_t& pos_b)
 {
     const unsigned long long ma = __ballot(pred_a), mb = __ballot(pred_b);
@@ -419,11 +419,11 @@ __device__ inline void block_append2(uint32_t* counters_a, bool pred_a, uint32_t
     const uint32_t shard = blockIdx.x & (FOVPT_SHARDS - 1);
     if (threadIdx.x == 0) {
         const uint32_t ta = a0 + a1 + a2 + a3;
-        s_scratch[8] = ta ? atomicAdd(&counters_a[shard], ta) : 0u;
+        s_scratch[8] = ta ? atomicAdd(&cnt->shard[shard][word_a], ta) : 0u;
     }
     if (threadIdx.x == 64) {
         const uint32_t tb = b0 + b1 + b2 + b3;
-        s_scratch[9] = tb ? atomicAdd(&counters_b[shard], tb) : 0u;
+        s_scratch[9] = tb ? atomicAdd(&cnt->shard[shard][word_b], tb) : 0u;
     }
     __syncthreads();
     pos_a = shard * cap + s_scratch[8] + (wave > 0 ? a0 : 0u) + (wave > 1 ? a1 : 0u) + (wave > 2 ? a2 : 0u) + pa;
@@ -434,10 +434,10 @@ __device__ inline void block_append2(uint32_t* counters_a, bool pred_a, uint32_t
 // logical index -> physical index of a sharded queue (all in scalar registers, no indexing)
 struct ShardMap {
     uint32_t p1, p2, p3, p4, p5, p6, p7, p8;     // exclusive prefix sums of the 8 shard counts (p0 = 0)
-    __device__ inline void load(const uint32_t* c)
+    __device__ inline void load(const Counters* cnt, int word)
     {
-        p1 = c[0]; p2 = p1 + c[1]; p3 = p2 + c[2]; p4 = p3 + c[3];
-        p5 = p4 + c[4]; p6 = p5 + c[5]; p7 = p6 + c[6]; p8 = p7 + c[7];
+        p1 = cnt->shard[0][word]; p2 = p1 + cnt->shard[1][word]; p3 = p2 + cnt->shard[2][word]; p4 = p3 + cnt->shard[3][word];
+        p5 = p4 + cnt->shard[4][word]; p6 = p5 + cnt->shard[5][word]; p7 = p6 + cnt->shard[6][word]; p8 = p7 + cnt->shard[7][word];
     }
     __device__ inline uint32_t total() const { return p8; }
     __device__ inline uint32_t phys(uint32_t i, uint32_t cap) const
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, Pat
                 ps.backplate[P.launch_base + (ly - P.row0) * P.gw + lx] = probe_eval(fd.probe, fd.probe_row_mul, u, v);
             }
         }
-        const uint32_t pos = block_append(cnt->q[0], cap, live, s_scratch);
+        const uint32_t pos = block_append(cnt, FOVPT_CNT_Q(0), cap, live, s_scratch);
         if (live) queue0[pos] = slot;
     }
 }
@@ -875,8 +875,8 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
 {
     __shared__ int s_stack[(FOVPT_STACK + 4) * FOVPT_QUADS_PER_BLOCK];  // + the end marker and three rows of slack above the top
     ShardMap ms, mq;
-    ms.load(cnt->sq[it_shadow >= 0 ? it_shadow : 0]);
-    mq.load(cnt->q[it_closest >= 0 ? it_closest : 0]);
+    ms.load(cnt, FOVPT_CNT_SQ(it_shadow >= 0 ? it_shadow : 0));
+    mq.load(cnt, FOVPT_CNT_Q(it_closest >= 0 ? it_closest : 0));
     const uint32_t n_sh = it_shadow >= 0 ? ms.total() : 0u;
     const uint32_t n_cl = it_closest >= 0 ? mq.total() : 0u;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
 {
     __shared__ uint32_t s_scratch[10];
     ShardMap mq;
-    mq.load(cnt->q[depth_iter]);
+    mq.load(cnt, FOVPT_CNT_Q(depth_iter));
     const uint32_t n = mq.total();
     const uint32_t nround = (n + FOVPT_BLOCK - 1) / FOVPT_BLOCK * FOVPT_BLOCK;
     for (uint32_t i = blockIdx.x * FOVPT_BLOCK + threadIdx.x; i < nround; i += gridDim.x * FOVPT_BLOCK) {
@@ -1102,15 +1102,15 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
             const unsigned long long below = (1ull << lane) - 1ull;
             uint32_t ba = 0, bb = 0;
             if (lane == 0) {
-                if (ma) ba = atomicAdd(&cnt->sq[depth_iter][shard], (uint32_t)__popcll(ma));
-                if (mb) bb = atomicAdd(&cnt->q[depth_iter + 1][shard], (uint32_t)__popcll(mb));
+                if (ma) ba = atomicAdd(&cnt->shard[shard][FOVPT_CNT_SQ(depth_iter)], (uint32_t)__popcll(ma));
+                if (mb) bb = atomicAdd(&cnt->shard[shard][FOVPT_CNT_Q(depth_iter + 1)], (uint32_t)__popcll(mb));
             }
             ba = __shfl(ba, 0); bb = __shfl(bb, 0);
             spos = shard * cap + ba + (uint32_t)__popcll(ma & below);
             qpos = shard * cap + bb + (uint32_t)__popcll(mb & below);
         }
 #else
-        block_append2(cnt->sq[depth_iter], want_shadow, cnt->q[depth_iter + 1], want_next, cap, s_scratch, spos, qpos);
+        block_append2(cnt, FOVPT_CNT_SQ(depth_iter), want_shadow, FOVPT_CNT_Q(depth_iter + 1), want_next, cap, s_scratch, spos, qpos);
 #endif
         if (want_shadow) { sq.o[spos] = sh_o; sq.d[spos] = sh_d; sq.val_vis[spos] = sh_vis; sq.val_occ[spos] = sh_occ; }
         if (want_next) queue_out[qpos] = slot;

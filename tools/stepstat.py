@@ -23,7 +23,8 @@ p, n = C.c_void_p(), C.c_size_t()
 lib.check(r._ctx, L.fovpt_debug_buffer(r._ctx, b"counters", C.byref(p), C.byref(n)))
 raw = np.empty(n.value, np.uint8)
 r.download(p.value, raw)
-diag = raw[4096 + 24:4096 + 24 + 64].view(np.uint64).reshape(2, 4)
+off = raw.size - 64          # the diag block is the tail of struct Counters
+diag = raw[off:off + 64].view(np.uint64).reshape(2, 4)
 rays = {"closest": st.radiance_rays, "any-hit": st.shadow_rays}
 for k, name in enumerate(("closest", "any-hit")):
     ns, nq, ls, lq = (int(x) for x in diag[k])
