@@ -8,7 +8,7 @@ import ctypes as C
 FOVPT_OK = 0
 MATERIAL_FLAG_SHADOW_CATCHER = 1
 
-OP_SIN, OP_COS, OP_ACOS, OP_ATAN2, OP_LOG, OP_POW, OP_SQRT, OP_DIV, OP_RSQRTD = range(1, 10)
+OP_SIN, OP_COS, OP_ACOS, OP_ATAN2, OP_LOG, OP_POW, OP_SQRT, OP_DIV, OP_RSQRTD, OP_UNORM8 = range(1, 11)
 
 
 class Float3(C.Structure):

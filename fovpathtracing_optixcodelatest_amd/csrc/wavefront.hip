@@ -242,15 +242,44 @@ __device__ inline float fresnel(float VDotN, float etaI, float etaT)          //
     float r2 = (LDotN - eta * VDotN) / (LDotN + eta * VDotN);
     return 0.5f * (sqr(r1) + sqr(r2));
 }
-__device__ float bsdf_pdf(const Mat& mat, float etaI, float etaO, const V3& n, const V3& V, const V3& L)   // :152-193
+// Terms of BSDFPdf / BSDFSample / BSDFEval that depend on the hit and the view direction only.  A hit
+// evaluates the BSDF for two light directions (the probe sample and the BSDF sample) and its pdf for
+// both: the reference recomputes these terms every time, here they are computed once -- the same
+// expressions on the same operands, hence the same bits.
+struct BsdfView {
+    float etaI, etaO;
+    float NDotV;          // dot(N, V)
+    float FrV;            // Fr(dot(N, V), etaI, etaO)                       :154, :199, :340
+    float a;              // max(0.001, roughness)
+    float GV_a, GV_q;     // SmithGGX(NDotV, a), SmithGGX(NDotV, 0.25)       :350, :375, :383
+    float FV;             // SchlickFresnel(NDotV)                           :362, :378
+    V3 Cspec0;            // :330-334
+};
+__device__ inline BsdfView bsdf_view(const Mat& mat, const V3& albedo, float etaI, float etaO, const V3& N, const V3& V)
+{
+    BsdfView w;
+    w.etaI = etaI; w.etaO = etaO;
+    w.NDotV = dot(N, V);
+    w.FrV = fresnel(w.NDotV, etaI, etaO);
+    w.a = fmaxf(0.001f, mat.roughness);
+    w.GV_a = smith_ggx(w.NDotV, w.a);
+    w.GV_q = smith_ggx(w.NDotV, .25f);
+    w.FV = schlick(w.NDotV);
+    const V3 Cdlin = albedo;
+    const float Cdlum = (float)(.3 * (double)Cdlin.x + .6 * (double)Cdlin.y + .1 * (double)Cdlin.z);
+    const V3 Ctint = Cdlum > 0.0f ? div_vs(Cdlin, Cdlum) : v3(1.0f);
+    w.Cspec0 = lerp3((float)((double)mat.specular * .08) * lerp3(v3(1.0f), Ctint, mat.specularTint), Cdlin, mat.metallic);
+    return w;
+}
+__device__ float bsdf_pdf(const Mat& mat, const BsdfView& w, const V3& n, const V3& V, const V3& L)   // :152-193
 {
     if (dot(L, n) <= 0.0f) {
         float bsdfPdf = 0.0f;
         float brdfPdf = kInv2Pi * mat.subsurface * 0.5f;
         return lerpf(brdfPdf, bsdfPdf, mat.transmission);
     }
-    float F = fresnel(dot(n, V), etaI, etaO);
-    const float a = fmaxf(0.001f, mat.roughness);
+    const float F = w.FrV;
+    const float a = w.a;
     const V3 half = safe_normalize(L + V);
     const float cosThetaHalf = fabsf(dot(half, n));
     const float pdfHalf = gtr2(cosThetaHalf, a) * cosThetaHalf;
@@ -274,19 +303,19 @@ __device__ inline V3 ggx_reflect(const Mat& mat, float r1, float r2, const V3& U
     return 2.0f * dot(view, half) * half - view;
 }
 // returns pdf; light = sampled direction
-__device__ float bsdf_sample(const Mat& mat, float etaI, float etaO, const V3& U, const V3& V, const V3& N,
+__device__ float bsdf_sample(const Mat& mat, const BsdfView& w, const V3& U, const V3& V, const V3& N,
                              const V3& view, V3& light, Rng& rng)             // :197-315
 {
     if (rng.randf() < mat.transmission) {
-        float F = fresnel(dot(N, view), etaI, etaO);
+        const float F = w.FrV;
         if (rng.randf() < F) {
             float r1 = rng.randf01();
             float r2 = rng.randf01();
             light = ggx_reflect(mat, r1, r2, U, V, N, view);
         } else {
             // Refract, :36-49
-            float eta = etaI / etaO;
-            float cosThetaI = dot(N, view);
+            float eta = w.etaI / w.etaO;
+            float cosThetaI = w.NDotV;
             float sin2ThetaI = fmaxf(0.0f, 1.0f - cosThetaI * cosThetaI);
             float sin2ThetaT = eta * eta * sin2ThetaI;
             if (sin2ThetaT >= 1) return 0.0f;
@@ -301,11 +330,11 @@ __device__ float bsdf_sample(const Mat& mat, float etaI, float etaO, const V3& U
             if (rng.randf() < mat.subsurface) {
                 // UniformSampleHemisphere, maths.h:243-254
                 float z = rng.randf01();
-                float w = sqrtf(1.0f - z * z);
+                float ww = sqrtf(1.0f - z * z);
                 float phi = k2Pi * rng.randf01();
                 float s, c;
                 fovpt_dm_sincos(phi, &s, &c);
-                float x = c * w, y = s * w;
+                float x = c * ww, y = s * ww;
                 light = U * x + V * y - N * z;
             } else {
                 // CosineSampleHemisphere, maths.h:256-277
@@ -321,31 +350,29 @@ __device__ float bsdf_sample(const Mat& mat, float etaI, float etaO, const V3& U
             light = ggx_reflect(mat, r1, r2, U, V, N, view);
         }
     }
-    return bsdf_pdf(mat, etaI, etaO, N, view, light);
+    return bsdf_pdf(mat, w, N, view, light);
 }
-__device__ V3 bsdf_eval(const Mat& mat, const V3& albedo, float etaI, float etaO, const V3& N, const V3& V, const V3& L)   // :318-427
+__device__ V3 bsdf_eval(const Mat& mat, const V3& albedo, const BsdfView& w, const V3& N, const V3& V, const V3& L)   // :318-427
 {
     float NDotL = dot(N, L);
-    float NDotV = dot(N, V);
+    const float NDotV = w.NDotV;
     V3 H = normalize(L + V);
     float NDotH = dot(N, H);
     float LDotH = dot(L, H);
-    V3 Cdlin = albedo;
-    float Cdlum = (float)(.3 * (double)Cdlin.x + .6 * (double)Cdlin.y + .1 * (double)Cdlin.z);
-    V3 Ctint = Cdlum > 0.0f ? div_vs(Cdlin, Cdlum) : v3(1.0f);
-    V3 Cspec0 = lerp3((float)((double)mat.specular * .08) * lerp3(v3(1.0f), Ctint, mat.specularTint), Cdlin, mat.metallic);
+    const V3 Cdlin = albedo;
+    const V3 Cspec0 = w.Cspec0;
     V3 bsdf = v3(0.0f);
     V3 brdf = v3(0.0f);
     if (mat.transmission > 0.0f) {
         if (NDotL <= 0) {
-            float F = fresnel(NDotV, etaI, etaO);
+            const float F = w.FrV;
             bsdf = v3(mat.transmission * (1.0f - F) / fabsf(NDotL) * (1.0f - mat.metallic));
         } else {
-            float a = fmaxf(0.001f, mat.roughness);
+            const float a = w.a;
             float Ds = gtr2(NDotH, a);
-            float FH = fresnel(LDotH, etaI, etaO);
+            float FH = fresnel(LDotH, w.etaI, w.etaO);
             V3 Fs = lerp3(Cspec0, v3(1.0f), FH);
-            float Gs = smith_ggx(NDotV, a) * smith_ggx(NDotL, a);
+            float Gs = w.GV_a * smith_ggx(NDotL, a);
             bsdf = Gs * Fs * Ds;
         }
     }
@@ -353,26 +380,27 @@ __device__ V3 bsdf_eval(const Mat& mat, const V3& albedo, float etaI, float etaO
         if (NDotL <= 0) {
             if (mat.subsurface > 0.0f) {
                 V3 s = v3(sqrtf(mat.color.x), sqrtf(mat.color.y), sqrtf(mat.color.z));
-                float FL = schlick(fabsf(NDotL)), FV = schlick(NDotV);
+                float FL = schlick(fabsf(NDotL)), FV = w.FV;
                 float Fd = (1.0f - 0.5f * FL) * (1.0f - 0.5f * FV);
                 brdf = kInvPi * s * mat.subsurface * Fd * (1.0f - mat.metallic);
             }
         } else {
-            float a = fmaxf(0.001f, mat.roughness);
+            const float a = w.a;
             float Ds = gtr2(NDotH, a);
             float FH = schlick(LDotH);
             V3 Fs = lerp3(Cspec0, v3(1.f), FH);
-            float Gs = smith_ggx(NDotV, a) * smith_ggx(NDotL, a);
-            float FL = schlick(NDotL), FV = schlick(NDotV);
+            float Gs = w.GV_a * smith_ggx(NDotL, a);
+            float FL = schlick(NDotL), FV = w.FV;
             float Fd90 = (float)(0.5 + (double)(2.0f * LDotH * LDotH * mat.roughness));
             float Fd = lerpf(1.0f, Fd90, FL) * lerpf(1.0f, Fd90, FV);
             float Dr = gtr1(NDotH, lerpf(.1f, .001f, mat.clearcoatGloss));
             float Fc = lerpf(.04f, 1.0f, FH);
-            float Gr = smith_ggx(NDotL, .25f) * smith_ggx(NDotV, .25f);
+            float Gr = smith_ggx(NDotL, .25f) * w.GV_q;
             brdf = add_vs(kInvPi * Fd * Cdlin * (1.0f - mat.metallic) * (1.0f - mat.subsurface) + Gs * Fs * Ds,
                           mat.clearcoat * Gr * Fc * Dr);
         }
     }
+    (void)NDotV;
     return lerp3(brdf, bsdf, mat.transmission);
 }
 
@@ -910,12 +938,25 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
 #define FLAG_DONE 1u
 #define FLAG_SECONDARY 2u
 
-__device__ inline float4 tex_texel(const TexDev& T, int x, int y)
+// (float)c / 255.0f for c = 0..255 without the division sequence: one Newton step on q = c * fl(1/255)
+// with fused multiply-adds gives the correctly rounded quotient for every one of the 256 inputs
+// (checked exhaustively: test_unorm8_device_matches_division, FOVPT_OP_UNORM8)
+__device__ inline float unorm8(uint32_t c)
 {
-    x %= T.w; if (x < 0) x += T.w;
-    y %= T.h; if (y < 0) y += T.h;
-    const uint32_t p = T.px[(size_t)y * T.w + x];
-    return make_float4((float)(p & 255u) / 255.0f, (float)((p >> 8) & 255u) / 255.0f, (float)((p >> 16) & 255u) / 255.0f, (float)(p >> 24) / 255.0f);
+    const float f = (float)c, r = 1.0f / 255.0f;
+    const float q = f * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, f), r, q);
+}
+__device__ inline float4 tex_unpack(uint32_t p)
+{
+    return make_float4(unorm8(p & 255u), unorm8((p >> 8) & 255u), unorm8((p >> 16) & 255u), unorm8(p >> 24));
+}
+// floor-mod of a texel coordinate (wrap addressing); a power-of-two size needs no division
+__device__ inline int tex_wrap(int x, int n)
+{
+    if ((n & (n - 1)) == 0) return x & (n - 1);
+    x %= n;
+    return x < 0 ? x + n : x;
 }
 // bilinear, wrap, normalized coordinates (the fp32 contract standing in for tex2D<float4>, :664)
 __device__ inline float4 tex2d(const TexDev& T, float u, float v)
@@ -923,8 +964,11 @@ __device__ inline float4 tex2d(const TexDev& T, float u, float v)
     const float x = u * (float)T.w - 0.5f, y = v * (float)T.h - 0.5f;
     const float fx0 = floorf(x), fy0 = floorf(y);
     const float fx = x - fx0, fy = y - fy0;
-    const int x0 = (int)fmaxf(-1.0e9f, fminf(1.0e9f, fx0)), y0 = (int)fmaxf(-1.0e9f, fminf(1.0e9f, fy0));
-    const float4 c00 = tex_texel(T, x0, y0), c10 = tex_texel(T, x0 + 1, y0), c01 = tex_texel(T, x0, y0 + 1), c11 = tex_texel(T, x0 + 1, y0 + 1);
+    const int x0 = tex_wrap((int)fmaxf(-1.0e9f, fminf(1.0e9f, fx0)), T.w), y0 = tex_wrap((int)fmaxf(-1.0e9f, fminf(1.0e9f, fy0)), T.h);
+    const int x1 = x0 + 1 == T.w ? 0 : x0 + 1, y1 = y0 + 1 == T.h ? 0 : y0 + 1;
+    const uint32_t* r0 = T.px + (size_t)y0 * T.w;
+    const uint32_t* r1 = T.px + (size_t)y1 * T.w;
+    const float4 c00 = tex_unpack(r0[x0]), c10 = tex_unpack(r0[x1]), c01 = tex_unpack(r1[x0]), c11 = tex_unpack(r1[x1]);
     const float w00 = (1.0f - fx) * (1.0f - fy), w10 = fx * (1.0f - fy), w01 = (1.0f - fx) * fy, w11 = fx * fy;
     return make_float4(w00 * c00.x + w10 * c10.x + w01 * c01.x + w11 * c11.x,
                        w00 * c00.y + w10 * c10.y + w01 * c01.y + w11 * c11.y,
@@ -1009,12 +1053,13 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
                     else
                         outEta = 1.0f;
                     // ---- SampleLights / SampleShadow :303-387 with the occlusion test deferred
+                    const BsdfView view = bsdf_view(mat, albedo, rayEta, outEta, N, wo);
                     V3 wi, skyColor; float skyPdf;
                     probe_sample(fd.probe, fd.guide_x, fd.guide_y, fd.probe_row_mul, wi, skyColor, skyPdf, rng);
                     V3 sum_hit = v3(0.0f);        // value of `sum` on the branch that evaluates the BSDF
                     {
-                        const float bsdfPdf = bsdf_pdf(mat, rayEta, outEta, N, wo, wi);
-                        const V3 f = bsdf_eval(mat, albedo, rayEta, outEta, N, wo, wi);
+                        const float bsdfPdf = bsdf_pdf(mat, view, N, wo, wi);
+                        const V3 f = bsdf_eval(mat, albedo, view, N, wo, wi);
                         if (bsdfPdf > 0.0f) {
                             const float weight = 0.5f * skyPdf / (0.5f * bsdfPdf + 0.5f * skyPdf);
                             if (weight > 0.0f) {
@@ -1043,7 +1088,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
                     V3 bu, bv;
                     basis_from_vector(N, bu, bv);
                     V3 bsdfDir = v3(0.f);
-                    const float bsdfPdf = bsdf_sample(mat, rayEta, outEta, bu, bv, N, wo, bsdfDir, rng);   // :706
+                    const float bsdfPdf = bsdf_sample(mat, view, bu, bv, N, wo, bsdfDir, rng);            // :706
                     if (alpha_set_one) flags |= FLAG_ALPHA_ONE;                            // :689 (kept even when DONE)
                     const bool same = rad_vis.x == rad_occ.x && rad_vis.y == rad_occ.y && rad_vis.z == rad_occ.z
                                    && alpha_vis.x == alpha_occ.x && alpha_vis.y == alpha_occ.y && alpha_vis.z == alpha_occ.z;
@@ -1071,7 +1116,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
                         } else {
                             *cell = f4(rad_occ, 0.f);
                         }
-                        const V3 f = bsdf_eval(mat, albedo, rayEta, outEta, N, wo, bsdfDir);   // :714
+                        const V3 f = bsdf_eval(mat, albedo, view, N, wo, bsdfDir);                  // :714
                         if (dot(bsdfDir, N) <= 0.0f) rayEta = outEta;                      // :717-721
                         thr = thr * div_vs(f * fabsf(dot(N, bsdfDir)), bsdfPdf);           // :724
                         flags |= FLAG_SECONDARY;
@@ -1370,6 +1415,7 @@ __global__ void k_math(int op, const float* a, const float* b, float* out, size_
     case FOVPT_OP_SQRT: r = sqrtf(a[i]); break;
     case FOVPT_OP_DIV: r = a[i] / b[i]; break;
     case FOVPT_OP_RSQRTD: r = (float)(1.0 / (double)sqrtf(a[i])); break;
+    case FOVPT_OP_UNORM8: r = unorm8((uint32_t)a[i] & 255u); break;
     }
     out[i] = r;
 }

@@ -43,6 +43,17 @@ def test_device_math_bits_unary(oracle, op, lo, hi):
     r.close()
 
 
+def test_unorm8_device_matches_division():
+    """The shading kernel turns a texel channel into c / 255.0f with two fmas; all 256 inputs, exact."""
+    from fovpathtracing_optixcodelatest_amd import renderer
+    r = renderer.SampleRenderer(scenes.cornell_box())
+    c = np.arange(256, dtype=np.float32)
+    got = r.debug_math(abi.OP_UNORM8, c)
+    want = (c / np.float32(255.0)).astype(np.float32)
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    r.close()
+
+
 @pytest.mark.parametrize("op", [abi.OP_ATAN2, abi.OP_POW, abi.OP_DIV])
 def test_device_math_bits_binary(oracle, op):
     from fovpathtracing_optixcodelatest_amd import renderer
