@@ -289,29 +289,23 @@ __device__ float bsdf_pdf(const Mat& mat, const BsdfView& w, const V3& n, const 
     float brdfPdf = lerpf(pdfDiff, pdfSpec, 0.5f);
     return lerpf(brdfPdf, bsdfPdf, mat.transmission);
 }
-__device__ inline V3 ggx_reflect(const Mat& mat, float r1, float r2, const V3& U, const V3& V, const V3& N, const V3& view)
-{
-    // shared by the two "sample specular" branches, Disney.cuh:211-226 and :287-307
-    const float a = fmaxf(0.001f, mat.roughness);
-    const float phiHalf = r1 * k2Pi;
-    const float cosThetaHalf = sqrtf((1.0f - r2) / (1.0f + (sqr(a) - 1.0f) * r2));
-    const float sinThetaHalf = sqrtf(fmaxf(0.0f, 1.0f - sqr(cosThetaHalf)));
-    float sinPhiHalf, cosPhiHalf;
-    fovpt_dm_sincos(phiHalf, &sinPhiHalf, &cosPhiHalf);
-    V3 half = U * (sinThetaHalf * cosPhiHalf) + V * (sinThetaHalf * sinPhiHalf) + N * cosThetaHalf;
-    if (dot(half, view) <= 0.0f) half = half * -1.0f;
-    return 2.0f * dot(view, half) * half - view;
-}
-// returns pdf; light = sampled direction
+// returns pdf; light = sampled direction.
+// The lanes of a wave take different branches of BSDFSample, and three of the four end in the same
+// work: one sincos and a change of basis.  The random numbers are drawn in the reference's order and
+// the branch is remembered; the sincos and (for both "sample specular" branches, Disney.cuh:211-226
+// and :287-307) the GGX half vector are then evaluated once for all lanes.
 __device__ float bsdf_sample(const Mat& mat, const BsdfView& w, const V3& U, const V3& V, const V3& N,
                              const V3& view, V3& light, Rng& rng)             // :197-315
 {
+    enum { SPECULAR, UNIFORM, COSINE };
+    int kind;
+    float r1, r2, z = 0.0f, angle;
     if (rng.randf() < mat.transmission) {
         const float F = w.FrV;
         if (rng.randf() < F) {
-            float r1 = rng.randf01();
-            float r2 = rng.randf01();
-            light = ggx_reflect(mat, r1, r2, U, V, N, view);
+            r1 = rng.randf01();
+            r2 = rng.randf01();
+            kind = SPECULAR;
         } else {
             // Refract, :36-49
             float eta = w.etaI / w.etaO;
@@ -324,31 +318,38 @@ __device__ float bsdf_sample(const Mat& mat, const BsdfView& w, const V3& U, con
             return (1.0f - F) * mat.transmission;
         }
     } else {
-        float r1 = rng.randf01();
-        float r2 = rng.randf01();
+        r1 = rng.randf01();
+        r2 = rng.randf01();
         if (rng.randf() < 0.5f) {
-            if (rng.randf() < mat.subsurface) {
-                // UniformSampleHemisphere, maths.h:243-254
-                float z = rng.randf01();
-                float ww = sqrtf(1.0f - z * z);
-                float phi = k2Pi * rng.randf01();
-                float s, c;
-                fovpt_dm_sincos(phi, &s, &c);
-                float x = c * ww, y = s * ww;
-                light = U * x + V * y - N * z;
-            } else {
-                // CosineSampleHemisphere, maths.h:256-277
-                float r = sqrtf(r1);
-                float theta = k2Pi * r2;
-                float s, c;
-                fovpt_dm_sincos(theta, &s, &c);
-                float sx = r * c, sy = r * s;
-                float z = sqrtf(fmaxf(0.0f, 1.0f - sx * sx - sy * sy));
-                light = U * sx + V * sy + N * z;
-            }
+            if (rng.randf() < mat.subsurface) { kind = UNIFORM; z = rng.randf01(); }
+            else kind = COSINE;
         } else {
-            light = ggx_reflect(mat, r1, r2, U, V, N, view);
+            kind = SPECULAR;
         }
+    }
+    if (kind == SPECULAR) angle = r1 * k2Pi;                   // phiHalf
+    else if (kind == COSINE) angle = k2Pi * r2;                // theta, maths.h:262
+    else angle = k2Pi * rng.randf01();                         // phi, maths.h:248
+    float sn, cs;
+    fovpt_dm_sincos(angle, &sn, &cs);
+    if (kind == SPECULAR) {
+        const float a = w.a;
+        const float cosThetaHalf = sqrtf((1.0f - r2) / (1.0f + (sqr(a) - 1.0f) * r2));
+        const float sinThetaHalf = sqrtf(fmaxf(0.0f, 1.0f - sqr(cosThetaHalf)));
+        V3 half = U * (sinThetaHalf * cs) + V * (sinThetaHalf * sn) + N * cosThetaHalf;
+        if (dot(half, view) <= 0.0f) half = half * -1.0f;
+        light = 2.0f * dot(view, half) * half - view;
+    } else if (kind == UNIFORM) {
+        // UniformSampleHemisphere, maths.h:243-254
+        const float ww = sqrtf(1.0f - z * z);
+        const float x = cs * ww, y = sn * ww;
+        light = U * x + V * y - N * z;
+    } else {
+        // CosineSampleHemisphere, maths.h:256-277
+        const float r = sqrtf(r1);
+        const float sx = r * cs, sy = r * sn;
+        const float zz = sqrtf(fmaxf(0.0f, 1.0f - sx * sx - sy * sy));
+        light = U * sx + V * sy + N * zz;
     }
     return bsdf_pdf(mat, w, N, view, light);
 }
