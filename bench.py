@@ -154,9 +154,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
+    gather_mode = "none" if world == 1 else ("host-synchronised (rehearsal)" if sync_gather else "async, overlapped with the next frame")
+    try:
+        for _ in range(args.warmup):
+            step()
+        fence()
+    except Exception as e:                                     # keep the run alive and say so in the JSON line
+        if world == 1 or sync_gather:
+            raise
+        sys.stderr.write("bench.py: stream-ordered gather failed (%s); falling back to a host-synchronised gather\n" % (e,))
+        sync_gather = True
+        gather_mode = "host-synchronised (fallback: %s)" % type(e).__name__
+        pending[0] = pending[1] = None
+        for _ in range(max(1, args.warmup)):
+            step()
+        fence()
     r.reset_stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -239,6 +251,7 @@ def main():
             "paths_per_frame": int(st.paths // max(1, args.steps)) if world == 1 else None,
             "rays_per_frame": rays_total / args.steps,
             "parallelism": "tile-shard x%d + RCCL reduce-gather" % world if world > 1 else "single GPU",
+            "gather": gather_mode,
         },
         "roofline": roofline,
     }
