@@ -710,6 +710,9 @@ struct QuadTrav {                                   // state of one ray's traver
     char* top;                                      // byte address of the first free stack row
     float lim;                                      // closest: prunes boxes beyond the quad-wide best hit
     float bt, bu, bv; uint32_t bpos, bprim;         // best hit among the triangles THIS lane tested
+#if FOVPT_V_STEPSTAT
+    uint32_t steps;                                 // diagnostics: node steps | leaf steps << 16 of this ray
+#endif
     // Row 0 holds the end marker, so "pop" needs no emptiness test; all row arithmetic stays in bytes.
     __device__ inline void start(int* stack, const QuadLane& q)
     {
@@ -841,12 +844,22 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
                               QuadTrav& T, unsigned long long* diag)
 {
     T.start(stack, q);
+#if FOVPT_V_STEPSTAT
+    uint32_t nn = 0, nl = 0;
     for (;;) {
-        while (T.cur >= 0) { STEPSTAT(diag); node_step<false>(sc, r, q, T); }
-        if (T.cur == TRAV_DONE) return;
+        while (T.cur >= 0) { STEPSTAT(diag); node_step<false>(sc, r, q, T); nn++; }
+        if (T.cur == TRAV_DONE) break;
         STEPSTAT(diag + 2);
+        leaf_step<false>(sc, r, q, T); nl++;
+    }
+    T.steps = nn | (nl << 16);
+#else
+    for (;;) {
+        while (T.cur >= 0) node_step<false>(sc, r, q, T);
+        if (T.cur == TRAV_DONE) return;
         leaf_step<false>(sc, r, q, T);
     }
+#endif
 }
 
 // Any-hit traversal over a POOL of shadow rays [first, end) owned by one wave: a quad that has finished
@@ -932,6 +945,9 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
         ray_setup(r, ps.ray_o[slot], ps.ray_d[slot]);
         traverse_quad(sc, r, stack, q, T, cnt->diag[0]);
         store_hit(ps, slot, T);
+#if FOVPT_V_STEPSTAT
+        if (q.j == 0) ((uint32_t*)&ps.ray_d[slot])[3] = T.steps;         // tools/raystat.py
+#endif
     }
 }
 
