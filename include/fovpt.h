@@ -194,7 +194,10 @@ void fovpt_destroy(fovpt_ctx* ctx);
 const char* fovpt_last_error(const fovpt_ctx* ctx);  /* ctx may be NULL: last create error */
 
 /* buildAccel + createTextures + buildSBT.  *traversable_out is what the reference
- * stores in launchParams.traversable (SimplePathtracer.cpp:61).                   */
+ * stores in launchParams.traversable (SimplePathtracer.cpp:61).  At most 2^26
+ * triangles in total (FOVPT_E_INVALID beyond: the traversal addresses the 48-byte
+ * triangle records and 128-byte nodes with 32-bit byte offsets); a hierarchy deeper
+ * than 21 four-wide levels is refused with FOVPT_E_BVH_DEPTH.                      */
 int fovpt_set_scene(fovpt_ctx* ctx, const fovpt_mesh_desc* meshes, int num_meshes,
                     const fovpt_texture_desc* textures, int num_textures,
                     uint64_t* traversable_out);
