@@ -35,13 +35,23 @@ struct EventPair { hipEvent_t a, b; int kind; };   // kind: 0 gen, 1 trace, 2 sh
 
 }  // namespace
 
+struct StateSet {
+    DevBuf s_ray_o, s_ray_d, s_thr, s_rng, s_hit, s_rad, s_alpha, s_backplate, s_guide_n, s_guide_a;
+    DevBuf q_a, q_b, sq_o[2], sq_d[2], sq_vis[2], sq_occ[2], counters;
+    hipEvent_t ev_shade[FOVPT_MAX_ITERS + 1] = {};
+    hipEvent_t ev_shadow[FOVPT_MAX_ITERS + 1] = {};
+    hipEvent_t ev_done = nullptr;          // recorded after the resolve of the last job that used this set
+    bool used = false;
+    DevBuf* all[27] = {&s_ray_o, &s_ray_d, &s_thr, &s_rng, &s_hit, &s_rad, &s_alpha, &s_backplate, &s_guide_n, &s_guide_a,
+                       &q_a, &q_b, &sq_o[0], &sq_d[0], &sq_vis[0], &sq_occ[0], &sq_o[1], &sq_d[1], &sq_vis[1], &sq_occ[1], &counters,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+
 struct fovpt_ctx {
     int device = 0;
     int num_cus = 256;
-    hipStream_t stream = nullptr;          // main chain: generate, closest-hit traversal, shade, resolve
-    hipStream_t shadow_stream = nullptr;   // occlusion rays of every bounce, off the critical path
-    hipEvent_t ev_shade[FOVPT_MAX_ITERS + 1] = {};
-    hipEvent_t ev_shadow[FOVPT_MAX_ITERS + 1] = {};
+    hipStream_t stream = nullptr;          // main chain: generate, closest-hit traversal, shade
+    hipStream_t shadow_stream = nullptr;   // occlusion rays of every bounce and the resolve: off the critical path
     std::string err;
     fovpt_config cfg;
     // scene
@@ -59,9 +69,10 @@ struct fovpt_ctx {
     bool rows_identical = false;           // every row of data / pdfX / cdfX equals row 0 bit for bit
     // frame buffers (resize)
     DevBuf fb_frame, fb_accum, fb_color, fb_normal, fb_albedo;
-    // wavefront state
-    DevBuf s_ray_o, s_ray_d, s_thr, s_rng, s_hit, s_rad, s_alpha, s_backplate, s_guide_n, s_guide_a;
-    DevBuf q_a, q_b, sq_o[2], sq_d[2], sq_vis[2], sq_occ[2], counters, spill, spill_shadow;
+    // Wavefront state, TWO sets used alternately by consecutive jobs: the tail of job k (its last occlusion
+    // rays and its resolve, on the shadow stream) runs beside the head of job k+1 (generate, camera rays)
+    StateSet set[2];
+    unsigned jobs = 0;                     // jobs issued so far; job j uses set[j & 1]
     int grid = 2048, grid_shadow = 1024;
     uint64_t slot_budget = 16ull << 20;    // sample slots per wavefront job (~1.3 KB of state and queues each)
     // stats
@@ -147,27 +158,27 @@ void free_scene(fovpt_ctx* c)
     c->has_scene = false;
 }
 
-int ensure_state(fovpt_ctx* c, size_t slots, size_t launches)
+int ensure_state(fovpt_ctx* c, StateSet& S, size_t slots, size_t launches)
 {
     const size_t v = 16;
-    HIPCHK(c, c->s_ray_o.reserve(slots * v)); HIPCHK(c, c->s_ray_d.reserve(slots * v));
-    HIPCHK(c, c->s_thr.reserve(slots * v)); HIPCHK(c, c->s_rng.reserve(slots * v));
-    HIPCHK(c, c->s_hit.reserve(slots * v)); HIPCHK(c, c->s_alpha.reserve(slots * v));
-    HIPCHK(c, c->s_rad.reserve(slots * v * (size_t)c->cfg.max_depth));
-    HIPCHK(c, c->s_backplate.reserve(launches * v));
-    if (c->cfg.write_guides) { HIPCHK(c, c->s_guide_n.reserve(slots * v)); HIPCHK(c, c->s_guide_a.reserve(slots * v)); }
+    HIPCHK(c, S.s_ray_o.reserve(slots * v)); HIPCHK(c, S.s_ray_d.reserve(slots * v));
+    HIPCHK(c, S.s_thr.reserve(slots * v)); HIPCHK(c, S.s_rng.reserve(slots * v));
+    HIPCHK(c, S.s_hit.reserve(slots * v)); HIPCHK(c, S.s_alpha.reserve(slots * v));
+    HIPCHK(c, S.s_rad.reserve(slots * v * (size_t)c->cfg.max_depth));
+    HIPCHK(c, S.s_backplate.reserve(launches * v));
+    if (c->cfg.write_guides) { HIPCHK(c, S.s_guide_n.reserve(slots * v)); HIPCHK(c, S.s_guide_a.reserve(slots * v)); }
     // sharded queues: FOVPT_SHARDS regions of `slots` entries each (memory is laid out for 288 GB);
     // the shadow queue is double-buffered because bounce it's occlusion rays may still be in flight
     // on the shadow stream while bounce it+1 is being shaded
     const size_t qn = slots * FOVPT_SHARDS;
-    HIPCHK(c, c->q_a.reserve(qn * 4)); HIPCHK(c, c->q_b.reserve(qn * 4));
+    HIPCHK(c, S.q_a.reserve(qn * 4)); HIPCHK(c, S.q_b.reserve(qn * 4));
     for (int k = 0; k < 2; k++) {
-        HIPCHK(c, c->sq_o[k].reserve(qn * v)); HIPCHK(c, c->sq_d[k].reserve(qn * v));
-        HIPCHK(c, c->sq_vis[k].reserve(qn * v)); HIPCHK(c, c->sq_occ[k].reserve(qn * v));
+        HIPCHK(c, S.sq_o[k].reserve(qn * v)); HIPCHK(c, S.sq_d[k].reserve(qn * v));
+        HIPCHK(c, S.sq_vis[k].reserve(qn * v)); HIPCHK(c, S.sq_occ[k].reserve(qn * v));
     }
-    if (!c->counters.p) {
-        HIPCHK(c, c->counters.reserve(sizeof(Counters)));
-        HIPCHK(c, hipMemsetAsync(c->counters.p, 0, sizeof(Counters), c->stream));
+    if (!S.counters.p) {
+        HIPCHK(c, S.counters.reserve(sizeof(Counters)));
+        HIPCHK(c, hipMemsetAsync(S.counters.p, 0, sizeof(Counters), c->stream));
     }
     return FOVPT_OK;
 }
@@ -199,8 +210,9 @@ int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passe
         c->stats.frames++;
         if (c->cfg.world > 1) {
             // foreign pixels are written as zero by whichever job wins them; holes must not keep stale sums
-            HIPCHK(c, hipMemsetAsync(lp->frame.frame_buffer, 0, (size_t)lp->frame.size.x * lp->frame.size.y * 4, c->stream));
-            HIPCHK(c, hipMemsetAsync(lp->frame.accum_buffer, 0, (size_t)lp->frame.size.x * lp->frame.size.y * 16, c->stream));
+            // (on the stream the resolves run on: after the previous frame's, before this frame's)
+            HIPCHK(c, hipMemsetAsync(lp->frame.frame_buffer, 0, (size_t)lp->frame.size.x * lp->frame.size.y * 4, c->shadow_stream));
+            HIPCHK(c, hipMemsetAsync(lp->frame.accum_buffer, 0, (size_t)lp->frame.size.x * lp->frame.size.y * 16, c->shadow_stream));
         }
         for (int p = 0; p < npass; p++) {
             const PassDev& P = passes_in[p];
@@ -266,28 +278,34 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     fd.tile_w = c->cfg.tile_w > 0 ? c->cfg.tile_w : 8; fd.tile_h = c->cfg.tile_h > 0 ? c->cfg.tile_h : 4;
 
     if (slots == 0) return FOVPT_OK;
-    int rc = ensure_state(c, (size_t)slots, (size_t)launches);
+    StateSet& S = c->set[c->jobs & 1u];
+    hipStream_t st = c->stream, ss = c->shadow_stream;
+    // the set is free once the resolve of the job that used it last has run (reserve() may also free and
+    // reallocate its buffers, which the runtime orders after all device work)
+    if (S.used) HIPCHK(c, hipStreamWaitEvent(st, S.ev_done, 0));
+    int rc = ensure_state(c, S, (size_t)slots, (size_t)launches);
     if (rc) return rc;
+    c->jobs++;
+    S.used = true;
 
     PathState ps;
-    ps.ray_o = (float4*)c->s_ray_o.p; ps.ray_d = (float4*)c->s_ray_d.p; ps.thr = (float4*)c->s_thr.p;
-    ps.rng = (uint4*)c->s_rng.p; ps.hit = (float4*)c->s_hit.p; ps.rad = (float4*)c->s_rad.p; ps.stride = (size_t)c->cfg.max_depth;
-    ps.alpha = (float4*)c->s_alpha.p; ps.backplate = (float4*)c->s_backplate.p;
-    ps.guide_n = c->cfg.write_guides ? (float4*)c->s_guide_n.p : nullptr;
-    ps.guide_a = c->cfg.write_guides ? (float4*)c->s_guide_a.p : nullptr;
+    ps.ray_o = (float4*)S.s_ray_o.p; ps.ray_d = (float4*)S.s_ray_d.p; ps.thr = (float4*)S.s_thr.p;
+    ps.rng = (uint4*)S.s_rng.p; ps.hit = (float4*)S.s_hit.p; ps.rad = (float4*)S.s_rad.p; ps.stride = (size_t)c->cfg.max_depth;
+    ps.alpha = (float4*)S.s_alpha.p; ps.backplate = (float4*)S.s_backplate.p;
+    ps.guide_n = c->cfg.write_guides ? (float4*)S.s_guide_n.p : nullptr;
+    ps.guide_a = c->cfg.write_guides ? (float4*)S.s_guide_a.p : nullptr;
     ShadowQueue sq[2];
     for (int k = 0; k < 2; k++) {
-        sq[k].o = (float4*)c->sq_o[k].p; sq[k].d = (float4*)c->sq_d[k].p;
-        sq[k].val_vis = (float4*)c->sq_vis[k].p; sq[k].val_occ = (float4*)c->sq_occ[k].p;
+        sq[k].o = (float4*)S.sq_o[k].p; sq[k].d = (float4*)S.sq_d[k].p;
+        sq[k].val_vis = (float4*)S.sq_vis[k].p; sq[k].val_occ = (float4*)S.sq_occ[k].p;
     }
     SceneView sc;
     sc.nodes = c->nodes; sc.tris = c->tris; sc.tri_tc = (const float2*)c->tri_tc.p;
     sc.meshes = (const MeshDev*)c->meshes.p; sc.textures = (const TexDev*)c->textures.p;
     sc.num_tris = c->num_tris; sc.any_catcher = c->any_catcher;
-    Counters* cnt = (Counters*)c->counters.p;
-    uint32_t* qa = (uint32_t*)c->q_a.p;
-    uint32_t* qb = (uint32_t*)c->q_b.p;
-    hipStream_t st = c->stream, ss = c->shadow_stream;
+    Counters* cnt = (Counters*)S.counters.p;
+    uint32_t* qa = (uint32_t*)S.q_a.p;
+    uint32_t* qb = (uint32_t*)S.q_b.p;
 
     HIPCHK(c, hipMemsetAsync(cnt, 0, offsetof(Counters, stat_radiance), st));
     const int grid = c->grid;
@@ -297,23 +315,24 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     // pass-throughs (which do not advance depth) when the scene holds a catcher
     int iters = c->cfg.max_depth + (c->any_catcher ? 1 + 24 : 0);
     if (iters > FOVPT_MAX_ITERS) iters = FOVPT_MAX_ITERS;
-    // Main chain (stream `st`):    generate, closest(0), shade(0), closest(1), shade(1), ... resolve
-    // Shadow chain (stream `ss`):  occlusion(it) as soon as shade(it) has queued its rays.
+    // Main chain (stream `st`):    generate, closest(0), shade(0), closest(1), shade(1), ... shade(D-1)
+    // Shadow chain (stream `ss`):  occlusion(it) as soon as shade(it) has queued its rays; then resolve.
     // Every radiance cell has one writer, so the only joins are: shade(it+2) reuses the shadow queue
-    // buffer of bounce it, and resolve needs everything.
+    // buffer of bounce it, and resolve needs everything -- it runs on the shadow stream, behind the last
+    // occlusion launch (which waited for the last shade), so the main chain is free for the next job.
     { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qa, sq[0], cap, cnt, 0, -1, grid); }
     for (int it = 0; it < iters; it++) {
-        if (it >= 2) HIPCHK(c, hipStreamWaitEvent(st, c->ev_shadow[it - 2], 0));
+        if (it >= 2) HIPCHK(c, hipStreamWaitEvent(st, S.ev_shadow[it - 2], 0));
         { Timed t(c, 2); fovpt_launch_shade(st, fd, sc, ps, qa, qb, sq[it & 1], cap, cnt, it, grid); }
-        HIPCHK(c, hipEventRecord(c->ev_shade[it], st));
-        HIPCHK(c, hipStreamWaitEvent(ss, c->ev_shade[it], 0));
+        HIPCHK(c, hipEventRecord(S.ev_shade[it], st));
+        HIPCHK(c, hipStreamWaitEvent(ss, S.ev_shade[it], 0));
         { Timed t(c, 3, ss); fovpt_launch_traverse(ss, sc, ps, qb, sq[it & 1], cap, cnt, -1, it, c->grid_shadow); }
-        HIPCHK(c, hipEventRecord(c->ev_shadow[it], ss));
+        HIPCHK(c, hipEventRecord(S.ev_shadow[it], ss));
         if (it + 1 < iters) { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qb, sq[0], cap, cnt, it + 1, -1, grid); }
         uint32_t* tmp = qa; qa = qb; qb = tmp;
     }
-    for (int it = iters >= 2 ? iters - 2 : 0; it < iters; it++) HIPCHK(c, hipStreamWaitEvent(st, c->ev_shadow[it], 0));
-    { Timed t(c, 4); fovpt_launch_resolve(st, fd, ps); }
+    { Timed t(c, 4, ss); fovpt_launch_resolve(ss, fd, ps); }
+    HIPCHK(c, hipEventRecord(S.ev_done, ss));
     HIPCHK(c, hipGetLastError());
     return FOVPT_OK;
 }
@@ -362,9 +381,12 @@ int fovpt_create(fovpt_ctx** out, int device)
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     e = hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_hi);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->shadow_stream, hipStreamDefault, prio_lo);
-    for (int k = 0; k <= FOVPT_MAX_ITERS && e == hipSuccess; k++) {
-        e = hipEventCreateWithFlags(&c->ev_shade[k], hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_shadow[k], hipEventDisableTiming);
+    for (StateSet& S : c->set) {
+        for (int k = 0; k <= FOVPT_MAX_ITERS && e == hipSuccess; k++) {
+            e = hipEventCreateWithFlags(&S.ev_shade[k], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&S.ev_shadow[k], hipEventDisableTiming);
+        }
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming);
     }
     if (e != hipSuccess) { delete c; return fail(nullptr, FOVPT_E_DEVICE, "stream/event creation: %s", hipGetErrorString(e)); }
     *out = c;
@@ -379,16 +401,17 @@ void fovpt_destroy(fovpt_ctx* c)
     (void)hipStreamSynchronize(c->shadow_stream);
     drain_events(c);
     for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
-    for (int k = 0; k <= FOVPT_MAX_ITERS; k++) {
-        if (c->ev_shade[k]) (void)hipEventDestroy(c->ev_shade[k]);
-        if (c->ev_shadow[k]) (void)hipEventDestroy(c->ev_shadow[k]);
+    for (StateSet& S : c->set) {
+        for (int k = 0; k <= FOVPT_MAX_ITERS; k++) {
+            if (S.ev_shade[k]) (void)hipEventDestroy(S.ev_shade[k]);
+            if (S.ev_shadow[k]) (void)hipEventDestroy(S.ev_shadow[k]);
+        }
+        if (S.ev_done) (void)hipEventDestroy(S.ev_done);
+        for (DevBuf* b : S.all) if (b) b->release();
     }
     free_scene(c);
     DevBuf* bufs[] = {&c->tri_tc, &c->meshes, &c->textures, &c->pr_data, &c->pr_pdfx, &c->pr_cdfx, &c->pr_pdfy, &c->pr_cdfy,
-                      &c->fb_frame, &c->fb_accum, &c->fb_color, &c->fb_normal, &c->fb_albedo,
-                      &c->s_ray_o, &c->s_ray_d, &c->s_thr, &c->s_rng, &c->s_hit, &c->s_rad, &c->s_alpha, &c->s_backplate, &c->s_guide_n, &c->s_guide_a,
-                      &c->q_a, &c->q_b, &c->sq_o[0], &c->sq_d[0], &c->sq_vis[0], &c->sq_occ[0],
-                      &c->sq_o[1], &c->sq_d[1], &c->sq_vis[1], &c->sq_occ[1], &c->counters, &c->spill, &c->spill_shadow};
+                      &c->fb_frame, &c->fb_accum, &c->fb_color, &c->fb_normal, &c->fb_albedo};
     for (DevBuf* b : bufs) b->release();
     (void)hipStreamDestroy(c->stream);
     (void)hipStreamDestroy(c->shadow_stream);
@@ -743,10 +766,12 @@ int fovpt_get_stats(fovpt_ctx* c, fovpt_stats* out)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
     drain_events(c);
-    if (c->counters.p) {
+    c->stats.radiance_rays = c->stats.shadow_rays = c->stats.paths = 0;
+    for (StateSet& S : c->set) {
+        if (!S.counters.p) continue;
         unsigned long long h[3];                          // stat_radiance, stat_shadow, stat_paths
-        HIPCHK(c, hipMemcpy(h, (const char*)c->counters.p + offsetof(Counters, stat_radiance), sizeof(h), hipMemcpyDeviceToHost));
-        c->stats.radiance_rays = h[0]; c->stats.shadow_rays = h[1]; c->stats.paths = h[2];
+        HIPCHK(c, hipMemcpy(h, (const char*)S.counters.p + offsetof(Counters, stat_radiance), sizeof(h), hipMemcpyDeviceToHost));
+        c->stats.radiance_rays += h[0]; c->stats.shadow_rays += h[1]; c->stats.paths += h[2];
     }
     *out = c->stats;
     return FOVPT_OK;
@@ -759,14 +784,18 @@ int fovpt_reset_stats(fovpt_ctx* c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
     drain_events(c);
-    if (c->counters.p) HIPCHK(c, hipMemset((char*)c->counters.p + offsetof(Counters, stat_radiance), 0, sizeof(Counters) - offsetof(Counters, stat_radiance)));
+    for (StateSet& S : c->set)
+        if (S.counters.p) HIPCHK(c, hipMemset((char*)S.counters.p + offsetof(Counters, stat_radiance), 0, sizeof(Counters) - offsetof(Counters, stat_radiance)));
     c->stats.radiance_rays = c->stats.shadow_rays = c->stats.paths = c->stats.frames = 0;
     c->stats.ms_generate = c->stats.ms_trace = c->stats.ms_shade = c->stats.ms_shadow = c->stats.ms_resolve = 0.0;
     c->stats.n_trace_launches = c->stats.n_shadow_launches = 0;
     return FOVPT_OK;
 }
 
-void* fovpt_stream(fovpt_ctx* c) { return c ? (void*)c->stream : nullptr; }
+// The stream on which frames COMPLETE, in order (occlusion rays and the resolve run on it): work a
+// caller queues on it after fovpt_render sees the finished frame and runs before the next frame's
+// resolve touches the render target.  (The head of a frame runs on an internal higher-priority stream.)
+void* fovpt_stream(fovpt_ctx* c) { return c ? (void*)c->shadow_stream : nullptr; }
 
 // ---- host helpers ------------------------------------------------------------------------
 // ProbeData::BuildCDF, PT_sv5_/Probe.h:29-77.  Strictly sequential fp32 sums: the order is part of
@@ -823,9 +852,10 @@ int fovpt_camera_uvw(const fovpt_float3* eye, const fovpt_float3* lookat, const 
 int fovpt_debug_buffer(fovpt_ctx* c, const char* name, void** ptr, size_t* bytes)
 {
     if (!c || !name || !ptr || !bytes) return FOVPT_E_INVALID;
+    StateSet& S = c->set[(c->jobs + 1u) & 1u];            // the set the most recent job used
     struct { const char* n; DevBuf* b; } tab[] = {
-        {"sq_o", &c->sq_o[1]}, {"sq_d", &c->sq_d[1]}, {"sq_vis", &c->sq_vis[1]}, {"sq_occ", &c->sq_occ[1]}, {"counters", &c->counters},
-        {"hit", &c->s_hit}, {"queue_a", &c->q_a}, {"queue_b", &c->q_b}, {"ray_o", &c->s_ray_o}, {"ray_d", &c->s_ray_d},
+        {"sq_o", &S.sq_o[1]}, {"sq_d", &S.sq_d[1]}, {"sq_vis", &S.sq_vis[1]}, {"sq_occ", &S.sq_occ[1]}, {"counters", &S.counters},
+        {"hit", &S.s_hit}, {"queue_a", &S.q_a}, {"queue_b", &S.q_b}, {"ray_o", &S.s_ray_o}, {"ray_d", &S.s_ray_d},
     };
     for (auto& t : tab)
         if (strcmp(t.n, name) == 0) { *ptr = t.b->p; *bytes = t.b->bytes; return FOVPT_OK; }

@@ -241,7 +241,10 @@ int fovpt_download(fovpt_ctx* ctx, const void* device_src, void* host_dst, size_
 
 int fovpt_get_stats(fovpt_ctx* ctx, fovpt_stats* out);   /* synchronises first */
 int fovpt_reset_stats(fovpt_ctx* ctx);
-void* fovpt_stream(fovpt_ctx* ctx);                      /* hipStream_t; SampleRenderer::stream */
+/* hipStream_t; SampleRenderer::stream.  Frames complete on it in submission order: work
+ * queued on it after fovpt_render / fovpt_launch sees the finished frame and is ordered
+ * before the next frame's writes to the render target.                              */
+void* fovpt_stream(fovpt_ctx* ctx);
 
 /* ---- host-side helpers that the reference runs on the CPU too ---------------- */
 /* ProbeData::BuildCDF (Probe.h:29-77): sequential fp32 accumulation, order preserved. */
