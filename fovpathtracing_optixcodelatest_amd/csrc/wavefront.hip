@@ -213,12 +213,11 @@ __device__ inline float schlick(float u)                                      //
     float m2 = m * m;
     return m2 * m2 * m;
 }
-__device__ inline float gtr1(float NDotH, float a)                            // :58-64
+__device__ inline float gtr1_pre(float NDotH, float a2, float log_a2)         // GTR1 :58-64 with a*a and log(a*a) given (a2 < 0: a >= 1)
 {
-    if (a >= 1) return kInvPi;
-    float a2 = a * a;
+    if (a2 < 0.0f) return kInvPi;
     float t = 1 + (a2 - 1) * NDotH * NDotH;
-    return (a2 - 1) / (kPi * fovpt_dm_logf(a2) * t);
+    return (a2 - 1) / (kPi * log_a2 * t);
 }
 __device__ inline float gtr2(float NDotH, float a)                            // :66-71
 {
@@ -254,6 +253,7 @@ struct BsdfView {
     float GV_a, GV_q;     // SmithGGX(NDotV, a), SmithGGX(NDotV, 0.25)       :350, :375, :383
     float FV;             // SchlickFresnel(NDotV)                           :362, :378
     V3 Cspec0;            // :330-334
+    float cc_a2, cc_log;  // clearcoat GTR1: a = mix(.1, .001, clearcoatGloss); a*a and log(a*a)    :381, :58-64
 };
 __device__ inline BsdfView bsdf_view(const Mat& mat, const V3& albedo, float etaI, float etaO, const V3& N, const V3& V)
 {
@@ -269,6 +269,9 @@ __device__ inline BsdfView bsdf_view(const Mat& mat, const V3& albedo, float eta
     const float Cdlum = (float)(.3 * (double)Cdlin.x + .6 * (double)Cdlin.y + .1 * (double)Cdlin.z);
     const V3 Ctint = Cdlum > 0.0f ? div_vs(Cdlin, Cdlum) : v3(1.0f);
     w.Cspec0 = lerp3((float)((double)mat.specular * .08) * lerp3(v3(1.0f), Ctint, mat.specularTint), Cdlin, mat.metallic);
+    const float cc_a = lerpf(.1f, .001f, mat.clearcoatGloss);
+    w.cc_a2 = cc_a >= 1 ? -1.0f : cc_a * cc_a;                  // -1: GTR1 returns 1/pi (a >= 1)
+    w.cc_log = cc_a >= 1 ? 0.0f : fovpt_dm_logf(w.cc_a2);
     return w;
 }
 __device__ float bsdf_pdf(const Mat& mat, const BsdfView& w, const V3& n, const V3& V, const V3& L)   // :152-193
@@ -364,16 +367,19 @@ __device__ V3 bsdf_eval(const Mat& mat, const V3& albedo, const BsdfView& w, con
     const V3 Cspec0 = w.Cspec0;
     V3 bsdf = v3(0.0f);
     V3 brdf = v3(0.0f);
+    // both lobes use the same D and G terms on the upper hemisphere (:346-351 and :371-376)
+    float Ds = 0.0f, Gs = 0.0f;
+    if (NDotL > 0) {
+        Ds = gtr2(NDotH, w.a);
+        Gs = w.GV_a * smith_ggx(NDotL, w.a);
+    }
     if (mat.transmission > 0.0f) {
         if (NDotL <= 0) {
             const float F = w.FrV;
             bsdf = v3(mat.transmission * (1.0f - F) / fabsf(NDotL) * (1.0f - mat.metallic));
         } else {
-            const float a = w.a;
-            float Ds = gtr2(NDotH, a);
             float FH = fresnel(LDotH, w.etaI, w.etaO);
             V3 Fs = lerp3(Cspec0, v3(1.0f), FH);
-            float Gs = w.GV_a * smith_ggx(NDotL, a);
             bsdf = Gs * Fs * Ds;
         }
     }
@@ -386,15 +392,12 @@ __device__ V3 bsdf_eval(const Mat& mat, const V3& albedo, const BsdfView& w, con
                 brdf = kInvPi * s * mat.subsurface * Fd * (1.0f - mat.metallic);
             }
         } else {
-            const float a = w.a;
-            float Ds = gtr2(NDotH, a);
             float FH = schlick(LDotH);
             V3 Fs = lerp3(Cspec0, v3(1.f), FH);
-            float Gs = w.GV_a * smith_ggx(NDotL, a);
             float FL = schlick(NDotL), FV = w.FV;
             float Fd90 = (float)(0.5 + (double)(2.0f * LDotH * LDotH * mat.roughness));
             float Fd = lerpf(1.0f, Fd90, FL) * lerpf(1.0f, Fd90, FV);
-            float Dr = gtr1(NDotH, lerpf(.1f, .001f, mat.clearcoatGloss));
+            float Dr = gtr1_pre(NDotH, w.cc_a2, w.cc_log);
             float Fc = lerpf(.04f, 1.0f, FH);
             float Gr = smith_ggx(NDotL, .25f) * w.GV_q;
             brdf = add_vs(kInvPi * Fd * Cdlin * (1.0f - mat.metallic) * (1.0f - mat.subsurface) + Gs * Fs * Ds,
