@@ -23,9 +23,6 @@
 #include "fovpt_device.h"
 #include "../../include/fovpt_detmath.h"
 
-#ifndef FOVPT_V_WAVEAPPEND
-#define FOVPT_V_WAVEAPPEND 0
-#endif
 #ifndef FOVPT_V_STEPSTAT
 #define FOVPT_V_STEPSTAT 0
 #endif
@@ -1159,24 +1156,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
         }
         // ---- wavefront-ballot compaction into the next queues
         uint32_t spos, qpos;
-#if FOVPT_V_WAVEAPPEND
-        {   // per-wave append (no barrier): one atomic per wave and queue on the wave's shard
-            const uint32_t lane = __lane_id();
-            const uint32_t shard = ((blockIdx.x << 2) + (threadIdx.x >> 6)) & (FOVPT_SHARDS - 1);
-            const unsigned long long ma = __ballot(want_shadow), mb = __ballot(want_next);
-            const unsigned long long below = (1ull << lane) - 1ull;
-            uint32_t ba = 0, bb = 0;
-            if (lane == 0) {
-                if (ma) ba = atomicAdd(&cnt->shard[shard][FOVPT_CNT_SQ(depth_iter)], (uint32_t)__popcll(ma));
-                if (mb) bb = atomicAdd(&cnt->shard[shard][FOVPT_CNT_Q(depth_iter + 1)], (uint32_t)__popcll(mb));
-            }
-            ba = __shfl(ba, 0); bb = __shfl(bb, 0);
-            spos = shard * cap + ba + (uint32_t)__popcll(ma & below);
-            qpos = shard * cap + bb + (uint32_t)__popcll(mb & below);
-        }
-#else
         block_append2(cnt, FOVPT_CNT_SQ(depth_iter), want_shadow, FOVPT_CNT_Q(depth_iter + 1), want_next, cap, s_scratch, spos, qpos);
-#endif
         if (want_shadow) { sq.o[spos] = sh_o; sq.d[spos] = sh_d; sq.val_vis[spos] = sh_vis; sq.val_occ[spos] = sh_occ; }
         if (want_next) queue_out[qpos] = slot;
     }
