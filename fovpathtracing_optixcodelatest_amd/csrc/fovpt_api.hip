@@ -307,7 +307,7 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     uint32_t* qa = (uint32_t*)S.q_a.p;
     uint32_t* qb = (uint32_t*)S.q_b.p;
 
-    HIPCHK(c, hipMemsetAsync(cnt, 0, offsetof(Counters, stat_radiance), st));
+    // (the queue counters are zero: at allocation, and again by the resolve of the set's previous job)
     const int grid = c->grid;
     const uint32_t cap = (uint32_t)slots;              // shard capacity: any shard may hold everything
     { Timed t(c, 0); fovpt_launch_generate(st, fd, ps, qa, cap, cnt, (uint32_t)slots, grid); }
@@ -331,7 +331,7 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
         if (it + 1 < iters) { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qb, sq[0], cap, cnt, it + 1, -1, grid); }
         uint32_t* tmp = qa; qa = qb; qb = tmp;
     }
-    { Timed t(c, 4, ss); fovpt_launch_resolve(ss, fd, ps); }
+    { Timed t(c, 4, ss); fovpt_launch_resolve(ss, fd, ps, cnt); }
     HIPCHK(c, hipEventRecord(S.ev_done, ss));
     HIPCHK(c, hipGetLastError());
     return FOVPT_OK;

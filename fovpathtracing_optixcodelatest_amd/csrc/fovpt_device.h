@@ -169,7 +169,7 @@ void fovpt_launch_traverse(hipStream_t st, SceneView sc, PathState ps, const uin
                            Counters* cnt, int it_closest, int it_shadow, int grid);
 void fovpt_launch_shade(hipStream_t st, const FrameDev& fd, SceneView sc, PathState ps, const uint32_t* queue_in, uint32_t* queue_out,
                         ShadowQueue sq, uint32_t cap, Counters* cnt, int depth, int grid);
-void fovpt_launch_resolve(hipStream_t st, const FrameDev& fd, PathState ps);
+void fovpt_launch_resolve(hipStream_t st, const FrameDev& fd, PathState ps, Counters* cnt);
 void fovpt_launch_build_guide(hipStream_t st, const float* cdf, int n, int segments, uint32_t* guide);
 void fovpt_launch_build_cdf(hipStream_t st, int w, int h, const float4* data, float* pdfX, float* cdfX, float* pdfY, float* cdfY, float* row_total);
 void fovpt_launch_math(hipStream_t st, int op, const float* a, const float* b, float* out, size_t n);

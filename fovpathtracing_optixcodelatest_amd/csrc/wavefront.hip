@@ -1218,8 +1218,14 @@ __device__ inline void writer_range(uint32_t x, uint32_t frame_dim, uint32_t fac
 //   C. the first n threads of the block each reduce one list entry: ordered sum over the launch index's
 //      sample slots and bounce cells, alpha, backplate mix, exposure, Reinhard, sRGB -> LDS
 //   D. every pixel thread fetches its colour from LDS and writes float4 accum + rgba8, coalesced
-__global__ __launch_bounds__(FOVPT_BLOCK) void k_resolve(const FrameDev fd, PathState ps)
+//   E. (block 0) the job's queue counters are zeroed for the next job that uses this state set: resolve
+//      is the last kernel of a job and nothing in it reads them
+__global__ __launch_bounds__(FOVPT_BLOCK) void k_resolve(const FrameDev fd, PathState ps, Counters* __restrict__ cnt)
 {
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        uint32_t* w = &cnt->shard[0][0];
+        for (uint32_t i = threadIdx.x; i < FOVPT_SHARDS * FOVPT_SHARD_STRIDE; i += FOVPT_BLOCK) w[i] = 0u;
+    }
     __shared__ uint32_t s_key[FOVPT_BLOCK];        // launch record id of the pixel's writer
     __shared__ uint32_t s_idx[FOVPT_BLOCK];        // leader thread -> tile list position
     __shared__ uint32_t s_list_li[FOVPT_BLOCK];    // tile list: launch index ...
@@ -1437,10 +1443,10 @@ void fovpt_launch_shade(hipStream_t st, const FrameDev& fd, SceneView sc, PathSt
 {
     hipLaunchKernelGGL(k_shade, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, sc, ps, queue_in, queue_out, sq, cap, cnt, depth);
 }
-void fovpt_launch_resolve(hipStream_t st, const FrameDev& fd, PathState ps)
+void fovpt_launch_resolve(hipStream_t st, const FrameDev& fd, PathState ps, Counters* cnt)
 {
     dim3 grid((fd.w + 63) / 64, (fd.h + 3) / 4);
-    hipLaunchKernelGGL(k_resolve, grid, dim3(FOVPT_BLOCK), 0, st, fd, ps);
+    hipLaunchKernelGGL(k_resolve, grid, dim3(FOVPT_BLOCK), 0, st, fd, ps, cnt);
 }
 void fovpt_launch_build_guide(hipStream_t st, const float* cdf, int n, int segments, uint32_t* guide)
 {
