@@ -374,6 +374,7 @@ int fovpt_create(fovpt_ctx** out, int device)
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
     c->grid = c->num_cus * 8;                 // 8 blocks of 256 = 32 waves per CU, grid-stride over the queues
     c->grid_shadow = c->num_cus * 6;          // occlusion launches (measured best of 2..8 with per-wave ray pools)
+    if (const char* g = getenv("FOVPT_GRID")) { const int v = atoi(g); if (v > 0 && v <= 16) c->grid = c->num_cus * v; }                 // tuning: blocks per CU
     if (const char* g = getenv("FOVPT_GRID_SHADOW")) { const int v = atoi(g); if (v > 0 && v <= 16) c->grid_shadow = c->num_cus * v; }   // tuning: blocks per CU
     if (const char* sb = getenv("FOVPT_SLOT_BUDGET")) { const long long v = atoll(sb); if (v > 0) c->slot_budget = (uint64_t)v; }   // tests: force chunking
     // the main chain is the critical path: give it the higher priority so occlusion waves only fill gaps
