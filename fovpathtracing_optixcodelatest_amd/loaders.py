@@ -208,3 +208,111 @@ def load_obj(obj_file: str) -> Model:
                 np.asarray(vtx, np.float32).reshape(-1, 3), np.asarray(idx, np.uint32).reshape(-1, 3), mat,
                 np.asarray(tcs, np.float32).reshape(-1, 2) if tcs else None, tex_id))
     return model
+
+
+# ------------------------------------------------------------------------------------------
+# Radiance .hdr environment maps -> float4 texels, as the reference's loadProbe gets them from
+# stbi_loadf(file, &w, &h, &channels, 4) (PT_sv5_/main.cpp:160-171; stb_image v2.x is vendored under
+# support/stb).  What is reproduced of stb's HDR reader:
+#   * header: first token "#?RADIANCE" or "#?RGBE"; lines up to the first empty one, among them
+#     "FORMAT=32-bit_rle_rgbe"; then "-Y <height> +X <width>" (the only orientation it accepts)
+#   * scanlines: new-style RLE (2, 2, width hi, width lo; four channel planes; count > 128 = run of
+#     count-128, else literal bytes) when 8 <= width < 32768, flat RGBE quadruples otherwise, and flat
+#     data also when the FIRST scanline does not start with the RLE marker
+#   * texel: (r, g, b) * 2^(e-136) as binary32 (exact: 8-bit mantissa times a power of two), alpha 1;
+#     e == 0 gives (0, 0, 0, 1).  No gamma, no scale, no vertical flip (linear data stays as it is).
+# ------------------------------------------------------------------------------------------
+def _rgbe_to_float4(rgbe: np.ndarray) -> np.ndarray:
+    """rgbe: (..., 4) uint8 -> (..., 4) float32."""
+    e = rgbe[..., 3].astype(np.int32)
+    f1 = np.ldexp(np.float32(1.0), e - 136).astype(np.float32)
+    out = np.empty(rgbe.shape[:-1] + (4,), np.float32)
+    out[..., :3] = rgbe[..., :3].astype(np.float32) * f1[..., None]
+    out[..., :3][e == 0] = 0.0
+    out[..., 3] = 1.0
+    return out
+
+
+def load_hdr(path: str) -> np.ndarray:
+    """Decode a Radiance RGBE file into an (H, W, 4) float32 array (row 0 = first scanline in the file)."""
+    with open(path, "rb") as f:
+        raw = f.read()
+    pos = 0
+
+    def token():
+        nonlocal pos
+        end = raw.find(b"\n", pos)
+        if end < 0:
+            end = len(raw)
+        line = raw[pos:end]
+        pos = min(len(raw), end + 1)
+        return line.decode("latin-1")
+
+    first = token()
+    if first not in ("#?RADIANCE", "#?RGBE"):
+        raise ValueError("%s: not a Radiance HDR file" % path)
+    valid = False
+    while True:
+        line = token()
+        if line == "":
+            break
+        if line == "FORMAT=32-bit_rle_rgbe":
+            valid = True
+        if pos >= len(raw):
+            break
+    if not valid:
+        raise ValueError("%s: unsupported HDR format (FORMAT=32-bit_rle_rgbe expected)" % path)
+    res = token()
+    parts = res.split()
+    if len(parts) != 4 or parts[0] != "-Y" or parts[2] != "+X":
+        raise ValueError("%s: unsupported HDR data layout %r (-Y h +X w expected)" % (path, res))
+    height, width = int(parts[1]), int(parts[3])
+    if width <= 0 or height <= 0:
+        raise ValueError("%s: bad HDR size" % path)
+    data = np.frombuffer(raw, np.uint8, offset=pos)
+
+    def flat(buf):
+        need = width * height * 4
+        if buf.size < need:
+            raise ValueError("%s: truncated HDR data" % path)
+        return _rgbe_to_float4(buf[:need].reshape(height, width, 4))
+
+    if width < 8 or width >= 32768:
+        return flat(data)
+    if data.size >= 4 and not (data[0] == 2 and data[1] == 2 and not (data[2] & 0x80)):
+        return flat(data)                      # old-style file: the bytes are plain pixels
+    rows = np.empty((height, width, 4), np.uint8)
+    p = 0
+    for j in range(height):
+        if p + 4 > data.size:
+            raise ValueError("%s: truncated HDR data" % path)
+        if data[p] != 2 or data[p + 1] != 2 or (data[p + 2] & 0x80):
+            raise ValueError("%s: scanline %d is not run-length encoded" % (path, j))
+        if ((int(data[p + 2]) << 8) | int(data[p + 3])) != width:
+            raise ValueError("%s: invalid decoded scanline length" % path)
+        p += 4
+        for k in range(4):
+            i = 0
+            while i < width:
+                if p >= data.size:
+                    raise ValueError("%s: truncated HDR data" % path)
+                count = int(data[p]); p += 1
+                if count > 128:
+                    count -= 128
+                    if count > width - i or p >= data.size:
+                        raise ValueError("%s: bad RLE data in HDR" % path)
+                    rows[j, i:i + count, k] = data[p]; p += 1
+                else:
+                    if count > width - i or p + count > data.size:
+                        raise ValueError("%s: bad RLE data in HDR" % path)
+                    if count == 0:
+                        raise ValueError("%s: bad RLE data in HDR (empty dump)" % path)
+                    rows[j, i:i + count, k] = data[p:p + count]; p += count
+                i += count
+    return _rgbe_to_float4(rows)
+
+
+def load_probe(hdr_file: str):
+    """loadProbe (PT_sv5_/main.cpp:160-171): texels from the file, then ProbeData::BuildCDF."""
+    from .renderer import ProbeData
+    return ProbeData(load_hdr(hdr_file)).BuildCDF()

@@ -52,3 +52,32 @@ def cfg_uniform(spp=4, max_depth=4):
     c.spp_uniform = spp
     c.max_depth = max_depth
     return c
+
+
+def encode_hdr_rle(texels_rgbe, comments=("# written by tests/common.py",), magic=b"#?RADIANCE"):
+    """A Radiance .hdr file (new-style RLE scanlines) holding the given (H, W, 4) uint8 RGBE texels."""
+    h, w, _ = texels_rgbe.shape
+    assert 8 <= w < 32768
+    out = bytearray(magic + b"\n")
+    for c in comments:
+        out += c.encode() + b"\n"
+    out += b"FORMAT=32-bit_rle_rgbe\n\n" + ("-Y %d +X %d\n" % (h, w)).encode()
+    for j in range(h):
+        out += bytes([2, 2, w >> 8, w & 255])
+        for k in range(4):
+            row = texels_rgbe[j, :, k]
+            i = 0
+            while i < w:
+                run = 1
+                while i + run < w and run < 127 and row[i + run] == row[i]:
+                    run += 1
+                if run >= 3:
+                    out += bytes([128 + run, int(row[i])])
+                    i += run
+                else:
+                    n = 1
+                    while i + n < w and n < 128 and not (i + n + 2 < w and row[i + n] == row[i + n + 1] == row[i + n + 2]):
+                        n += 1
+                    out += bytes([n]) + bytes(row[i:i + n].tolist())
+                    i += n
+    return bytes(out)

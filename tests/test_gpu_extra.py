@@ -306,3 +306,22 @@ def test_obj_loaded_textured_scene(oracle, tmp_path):
     oracle.render(S, F, cfg)
     assert _bits_equal(r.downloadAccum(), F.accum) and np.array_equal(r.downloadPixels(), F.frame)
     r.close()
+
+
+def test_probe_loaded_from_a_radiance_hdr_file(oracle, tmp_path):
+    """loadProbe (main.cpp:160-171): texels decoded from an .hdr file feed ProbeSample / ProbeEval on both sides."""
+    from common import encode_hdr_rle
+    from fovpathtracing_optixcodelatest_amd import loaders
+    rng = np.random.default_rng(7)
+    rgbe = rng.integers(1, 256, (16, 32, 4), dtype=np.uint8)
+    rgbe[..., 3] = rng.integers(126, 131, (16, 32))
+    rgbe[3, 20:23] = (255, 250, 240, 137)                       # a small sun: high contrast for the CDF searches
+    (tmp_path / "sky.hdr").write_bytes(encode_hdr_rle(rgbe))
+    data = loaders.load_hdr(str(tmp_path / "sky.hdr"))
+    size, cfg = (160, 96), cfg_foveated(12, 36, (1, 2, 8))
+    r = make_gpu(scenes.cornell_box(), data, scenes.CORNELL_CAMERA, size, cfg)
+    r.render()
+    S, F = make_oracle(oracle, scenes.cornell_box(), data, scenes.CORNELL_CAMERA, size)
+    oracle.render(S, F, cfg)
+    assert _bits_equal(r.downloadAccum(), F.accum) and np.array_equal(r.downloadPixels(), F.frame)
+    r.close()

@@ -97,3 +97,70 @@ def test_loaded_model_packs_for_the_c_abi(obj_dir):
     m = loaders.load_obj(os.path.join(obj_dir, "test.obj"))
     md, n, td, nt, keep = pack_model(m)
     assert n == 3 and nt == 1 and md[0].num_triangles == 2 and md[0].texture_id == 0 and td[0].width == 2
+
+
+# ---- Radiance .hdr environment maps (loadProbe, PT_sv5_/main.cpp:160-171 -> stbi_loadf) ---------------
+def _expected_texels(rgbe):
+    want = np.zeros(rgbe.shape[:2] + (4,), np.float32)
+    for j in range(rgbe.shape[0]):
+        for i in range(rgbe.shape[1]):
+            r, g, b, e = (int(x) for x in rgbe[j, i])
+            if e:
+                f1 = np.float32(2.0 ** (e - 136))                 # ldexp(1.0f, e - (128 + 8))
+                want[j, i, :3] = np.float32([r, g, b]) * f1
+            want[j, i, 3] = 1.0
+    return want
+
+
+def test_hdr_rle_scanlines_decode_like_stbi_loadf(tmp_path):
+    from common import encode_hdr_rle
+    rng = np.random.default_rng(0)
+    rgbe = rng.integers(0, 256, (6, 16, 4), dtype=np.uint8)
+    rgbe[..., 3] = rng.integers(118, 142, (6, 16))
+    rgbe[2, :, 0] = 7                         # a long run
+    rgbe[3, 4:12, 3] = 0                      # exponent 0: black texels, alpha stays 1
+    p = tmp_path / "a.hdr"
+    p.write_bytes(encode_hdr_rle(rgbe, comments=("# c", "EXPOSURE=1.0")))
+    got = loaders.load_hdr(str(p))
+    assert got.dtype == np.float32 and got.shape == (6, 16, 4)
+    assert np.array_equal(got.view(np.uint32), _expected_texels(rgbe).view(np.uint32))
+    assert np.all(got[3, 4:12, :3] == 0) and np.all(got[..., 3] == 1)
+
+
+def test_hdr_flat_data_and_rgbe_magic(tmp_path):
+    rng = np.random.default_rng(1)
+    narrow = rng.integers(1, 256, (3, 4, 4), dtype=np.uint8)          # width < 8: always flat
+    p = tmp_path / "n.hdr"
+    p.write_bytes(b"#?RGBE\nFORMAT=32-bit_rle_rgbe\n\n-Y 3 +X 4\n" + narrow.tobytes())
+    assert np.array_equal(loaders.load_hdr(str(p)), _expected_texels(narrow))
+    wide = rng.integers(130, 256, (2, 9, 4), dtype=np.uint8)          # old-style file: no (2, 2) marker on scanline 0
+    q = tmp_path / "w.hdr"
+    q.write_bytes(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 2 +X 9\n" + wide.tobytes())
+    assert np.array_equal(loaders.load_hdr(str(q)), _expected_texels(wide))
+
+
+@pytest.mark.parametrize("blob", [
+    b"#?NOPE\nFORMAT=32-bit_rle_rgbe\n\n-Y 1 +X 1\n\x01\x02\x03\x80",
+    b"#?RADIANCE\nFORMAT=32-bit_rle_xyze\n\n-Y 1 +X 1\n\x01\x02\x03\x80",
+    b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n+Y 1 +X 1\n\x01\x02\x03\x80",
+    b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 2 +X 2\n\x01\x02\x03\x80",                      # truncated
+    b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 1 +X 8\n\x02\x02\x00\x09" + b"\x88\x01" * 4,     # wrong scanline length
+    b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n-Y 1 +X 8\n\x02\x02\x00\x08" + b"\x89\x01" * 4,     # run past the end
+])
+def test_hdr_rejects_what_stb_rejects(tmp_path, blob):
+    p = tmp_path / "bad.hdr"
+    p.write_bytes(blob)
+    with pytest.raises(ValueError):
+        loaders.load_hdr(str(p))
+
+
+def test_load_probe_builds_the_cdf(tmp_path):
+    from common import encode_hdr_rle
+    rng = np.random.default_rng(2)
+    rgbe = rng.integers(1, 256, (8, 16, 4), dtype=np.uint8)
+    rgbe[..., 3] = rng.integers(124, 134, (8, 16))
+    p = tmp_path / "sky.hdr"
+    p.write_bytes(encode_hdr_rle(rgbe))
+    probe = loaders.load_probe(str(p))
+    assert probe.valid and (probe.width, probe.height) == (16, 8)
+    assert np.all(np.diff(probe.cdfValuesX, axis=1) >= 0) and probe.cdfValuesY[-1] == pytest.approx(1.0, rel=1e-5)
