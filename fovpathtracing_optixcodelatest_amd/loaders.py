@@ -316,3 +316,154 @@ def load_probe(hdr_file: str):
     """loadProbe (PT_sv5_/main.cpp:160-171): texels from the file, then ProbeData::BuildCDF."""
     from .renderer import ProbeData
     return ProbeData(load_hdr(hdr_file)).BuildCDF()
+
+
+# ------------------------------------------------------------------------------------------
+# glTF 2.0 (.gltf, JSON + external or data-URI buffers) -> Model.  In the reference tinygltf feeds only the
+# SDK's sutil::Scene (sutil/Scene.cpp:109-442), never `Model`; this is the glue BASELINE.json's Bistro
+# configuration needs, with sutil's traversal rules:
+#   * root nodes are the nodes that are nobody's child (`scenes` is ignored, :425-437)
+#   * node transform = parent * matrix * T * R * S in binary32 (:148); `matrix` is column-major in the file
+#   * a camera node is skipped; a node WITH a mesh contributes its primitives and its children are NOT
+#     visited; only a node without camera and mesh descends (:150-251)
+#   * only TRIANGLES primitives (mode 4, the default); anything else is skipped (:181-185)
+#   * materials: pbrMetallicRoughness baseColorFactor / roughnessFactor / metallicFactor / baseColorTexture
+#     (:333-418)
+# and the conventions of the OBJ path for what `Model` needs beyond that: one TriangleMesh per primitive with
+# vertices in world space, Material() constructor defaults with color / roughness / metallic from the file and
+# emission = emissiveFactor (0 when absent, like a missing Ke), texture id -1 when the image cannot be decoded.
+# ------------------------------------------------------------------------------------------
+_GLTF_COMP = {5120: np.int8, 5121: np.uint8, 5122: np.int16, 5123: np.uint16, 5125: np.uint32, 5126: np.float32}
+_GLTF_NCOMP = {"SCALAR": 1, "VEC2": 2, "VEC3": 3, "VEC4": 4, "MAT4": 16}
+
+
+def _m4(rows):
+    return np.array(rows, np.float32).reshape(4, 4)
+
+
+def _quat_matrix(x, y, z, w):
+    """sutil::Quaternion(w, x, y, z).rotationMatrix() (sutil/Quaternion.h:239-269): binary32, the quaternion
+    is used as given (not normalised), same operation order."""
+    qw, qx, qy, qz = (np.float32(v) for v in (w, x, y, z))
+    one, two = np.float32(1), np.float32(2)
+    return _m4([[one - two * qy * qy - two * qz * qz, two * qx * qy - two * qz * qw, two * qx * qz + two * qy * qw, 0],
+                [two * qx * qy + two * qz * qw, one - two * qx * qx - two * qz * qz, two * qy * qz - two * qx * qw, 0],
+                [two * qx * qz - two * qy * qw, two * qy * qz + two * qx * qw, one - two * qx * qx - two * qy * qy, 0],
+                [0, 0, 0, 1]])
+
+
+def load_gltf(gltf_file: str) -> Model:
+    import base64
+    import json
+    base = os.path.dirname(os.path.abspath(gltf_file))
+    with open(gltf_file, "r") as f:
+        g = json.load(f)
+
+    def read_uri(uri: str) -> bytes:
+        if uri.startswith("data:"):
+            return base64.b64decode(uri.split(",", 1)[1])
+        with open(os.path.join(base, uri), "rb") as fh:
+            return fh.read()
+
+    buffers = [read_uri(b["uri"]) for b in g.get("buffers", [])]
+
+    def accessor(idx: int) -> np.ndarray:
+        a = g["accessors"][idx]
+        dt, nc, count = np.dtype(_GLTF_COMP[a["componentType"]]), _GLTF_NCOMP[a["type"]], a["count"]
+        if "bufferView" not in a:
+            return np.zeros((count, nc), dt)
+        bv = g["bufferViews"][a["bufferView"]]
+        off = bv.get("byteOffset", 0) + a.get("byteOffset", 0)
+        elem = dt.itemsize * nc
+        stride = bv.get("byteStride", 0) or elem
+        raw = np.frombuffer(buffers[bv["buffer"]], np.uint8, count=(count - 1) * stride + elem if count else 0, offset=off)
+        if stride == elem:
+            out = raw.view(dt).reshape(count, nc)
+        else:
+            out = np.stack([raw[i * stride:i * stride + elem].view(dt) for i in range(count)]).reshape(count, nc)
+        if a.get("normalized") and dt.kind in "ui":
+            scale = np.float32(np.iinfo(dt).max)
+            out = np.maximum(out.astype(np.float32) / scale, np.float32(-1.0))
+        return out
+
+    model = Model()
+    tex_cache: Dict[int, int] = {}
+
+    def texture_id(tex_index: Optional[int]) -> int:
+        if tex_index is None:
+            return -1
+        if tex_index in tex_cache:
+            return tex_cache[tex_index]
+        tid = -1
+        try:
+            img = g["images"][g["textures"][tex_index]["source"]]
+            if "uri" in img and not img["uri"].startswith("data:"):
+                px = _load_texture(os.path.join(base, img["uri"]))
+                if px is not None:
+                    model.textures.append(px)
+                    tid = len(model.textures) - 1
+        except (KeyError, IndexError):
+            tid = -1
+        tex_cache[tex_index] = tid
+        return tid
+
+    def material(idx: Optional[int]):
+        m = Material.reference_default()
+        m.emission.set((0.0, 0.0, 0.0))
+        tid = -1
+        if idx is not None and 0 <= idx < len(g.get("materials", [])):
+            gm = g["materials"][idx]
+            pbr = gm.get("pbrMetallicRoughness", {})
+            c = pbr.get("baseColorFactor", [1.0, 1.0, 1.0, 1.0])
+            m.color.set((float(c[0]), float(c[1]), float(c[2])))
+            m.roughness = float(pbr.get("roughnessFactor", 1.0))
+            m.metallic = float(pbr.get("metallicFactor", 1.0))
+            e = gm.get("emissiveFactor", [0.0, 0.0, 0.0])
+            m.emission.set((float(e[0]), float(e[1]), float(e[2])))
+            if "baseColorTexture" in pbr:
+                tid = texture_id(pbr["baseColorTexture"].get("index"))
+        return m, tid
+
+    nodes = g.get("nodes", [])
+    is_root = [True] * len(nodes)
+    for n in nodes:
+        for ch in n.get("children", []):
+            is_root[ch] = False
+
+    def visit(node: dict, parent: np.ndarray):
+        t = node.get("translation")
+        T = _m4([[1, 0, 0, t[0]], [0, 1, 0, t[1]], [0, 0, 1, t[2]], [0, 0, 0, 1]]) if t else np.eye(4, dtype=np.float32)
+        r = node.get("rotation")
+        R = _quat_matrix(*r) if r else np.eye(4, dtype=np.float32)
+        s = node.get("scale")
+        S = _m4([[s[0], 0, 0, 0], [0, s[1], 0, 0], [0, 0, s[2], 0], [0, 0, 0, 1]]) if s else np.eye(4, dtype=np.float32)
+        mm = node.get("matrix")
+        M = np.array(mm, np.float32).reshape(4, 4).T if mm else np.eye(4, dtype=np.float32)     # column-major in the file
+        xf = ((((parent @ M).astype(np.float32) @ T).astype(np.float32) @ R).astype(np.float32) @ S).astype(np.float32)
+        if "camera" in node:
+            return
+        if "mesh" in node:
+            for prim in g["meshes"][node["mesh"]].get("primitives", []):
+                if prim.get("mode", 4) != 4:
+                    continue
+                pos = accessor(prim["attributes"]["POSITION"]).astype(np.float32)
+                world = (pos @ xf[:3, :3].T + xf[:3, 3]).astype(np.float32)
+                if "indices" in prim:
+                    idx = accessor(prim["indices"]).astype(np.uint32).reshape(-1)
+                else:
+                    idx = np.arange(pos.shape[0], dtype=np.uint32)
+                idx = idx[:idx.size // 3 * 3].reshape(-1, 3)
+                tc = None
+                if "TEXCOORD_0" in prim["attributes"]:
+                    tc = np.ascontiguousarray(accessor(prim["attributes"]["TEXCOORD_0"]).astype(np.float32)[:, :2])
+                mat, tid = material(prim.get("material"))
+                model.meshes.append(TriangleMesh(vertex=np.ascontiguousarray(world), index=np.ascontiguousarray(idx), material=mat,
+                                                 texcoord=tc, texture_id=tid if tc is not None else -1))
+            return                                  # sutil does not descend below a mesh node
+        for ch in node.get("children", []):
+            visit(nodes[ch], xf)
+
+    for i, n in enumerate(nodes):
+        if is_root[i]:
+            visit(n, np.eye(4, dtype=np.float32))
+    return model

@@ -325,3 +325,39 @@ def test_probe_loaded_from_a_radiance_hdr_file(oracle, tmp_path):
     oracle.render(S, F, cfg)
     assert _bits_equal(r.downloadAccum(), F.accum) and np.array_equal(r.downloadPixels(), F.frame)
     r.close()
+
+
+def test_gltf_loaded_scene(oracle, tmp_path):
+    """glTF -> Model through loaders.load_gltf (sutil::Scene's node rules), rendered on both sides."""
+    import base64
+    import json
+    from fovpathtracing_optixcodelatest_amd import loaders
+    quad = np.array([[-1, 0, -1], [1, 0, -1], [1, 0, 1], [-1, 0, 1]], np.float32)
+    idx = np.array([0, 2, 1, 0, 3, 2], np.uint16)
+    blob = quad.tobytes() + idx.tobytes()
+    uri = "data:application/octet-stream;base64," + base64.b64encode(blob).decode()
+    g = {"asset": {"version": "2.0"}, "buffers": [{"byteLength": len(blob), "uri": uri}],
+         "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 48}, {"buffer": 0, "byteOffset": 48, "byteLength": 12}],
+         "accessors": [{"bufferView": 0, "componentType": 5126, "count": 4, "type": "VEC3"},
+                       {"bufferView": 1, "componentType": 5123, "count": 6, "type": "SCALAR"}],
+         "materials": [{"pbrMetallicRoughness": {"baseColorFactor": [0.7, 0.7, 0.7, 1], "roughnessFactor": 0.6, "metallicFactor": 0.0}},
+                       {"pbrMetallicRoughness": {"baseColorFactor": [0.9, 0.2, 0.1, 1], "roughnessFactor": 0.2, "metallicFactor": 0.8},
+                        "emissiveFactor": [2, 2, 2]}],
+         "meshes": [{"primitives": [{"attributes": {"POSITION": 0}, "indices": 1, "material": 0}]},
+                    {"primitives": [{"attributes": {"POSITION": 0}, "indices": 1, "material": 1}]}],
+         "nodes": [{"mesh": 0, "scale": [6, 1, 6]},
+                   {"children": [2, 3], "translation": [0, 1.2, 0]},
+                   {"mesh": 1, "rotation": [0.38268343, 0, 0, 0.92387953], "scale": [0.8, 1, 0.8]},
+                   {"mesh": 1, "translation": [2.2, 0.4, -1], "rotation": [0, 0, 0.70710678, 0.70710678]}]}
+    (tmp_path / "s.gltf").write_text(json.dumps(g))
+    model = loaders.load_gltf(str(tmp_path / "s.gltf"))
+    assert model.num_triangles == 6
+    cam = dict(eye=(5.0, 4.0, 7.0), lookat=(0.0, 0.8, 0.0), up=(0.0, 1.0, 0.0), fovy=45.0)
+    size, cfg = (160, 96), cfg_foveated(12, 36, (1, 2, 8))
+    r = make_gpu(model, scenes.sky_probe(), cam, size, cfg)
+    r.render()
+    S, F = make_oracle(oracle, model, scenes.sky_probe(), cam, size)
+    oracle.render(S, F, cfg)
+    assert _bits_equal(r.downloadAccum(), F.accum) and np.array_equal(r.downloadPixels(), F.frame)
+    assert int((r.downloadPixels() != 0).sum()) > 0.5 * size[0] * size[1]
+    r.close()

@@ -164,3 +164,68 @@ def test_load_probe_builds_the_cdf(tmp_path):
     probe = loaders.load_probe(str(p))
     assert probe.valid and (probe.width, probe.height) == (16, 8)
     assert np.all(np.diff(probe.cdfValuesX, axis=1) >= 0) and probe.cdfValuesY[-1] == pytest.approx(1.0, rel=1e-5)
+
+
+# ---- glTF 2.0 -> Model with sutil::Scene's traversal rules (sutil/Scene.cpp:109-442) ------------------
+def _gltf_fixture(tmp_path):
+    import base64
+    import json
+    pos = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0]], np.float32)
+    idx = np.array([0, 1, 2, 2, 1, 3], np.uint16)
+    tc = np.array([[0, 0], [1, 0], [0, 1], [1, 1]], np.float32)
+    blob = pos.tobytes() + idx.tobytes() + tc.tobytes()
+    (tmp_path / "geo.bin").write_bytes(blob)
+    col_major = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 10, 20, 30, 1]            # translation (10, 20, 30), column-major
+    g = {"asset": {"version": "2.0"},
+         "buffers": [{"byteLength": len(blob), "uri": "geo.bin"},
+                     {"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}],
+         "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 48}, {"buffer": 1, "byteOffset": 48, "byteLength": 12},
+                         {"buffer": 0, "byteOffset": 60, "byteLength": 32}],
+         "accessors": [{"bufferView": 0, "componentType": 5126, "count": 4, "type": "VEC3"},
+                       {"bufferView": 1, "componentType": 5123, "count": 6, "type": "SCALAR"},
+                       {"bufferView": 2, "componentType": 5126, "count": 4, "type": "VEC2"}],
+         "materials": [{"pbrMetallicRoughness": {"baseColorFactor": [0.2, 0.4, 0.6, 1], "roughnessFactor": 0.3, "metallicFactor": 0.1},
+                        "emissiveFactor": [1, 2, 3]}, {}],
+         "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "TEXCOORD_0": 2}, "indices": 1, "material": 0},
+                                    {"attributes": {"POSITION": 0}, "mode": 1}]},                    # LINES: skipped
+                    {"primitives": [{"attributes": {"POSITION": 0}, "material": 1}]}],               # not indexed: 1 triangle
+         "cameras": [{"type": "perspective", "perspective": {"yfov": 0.8, "znear": 0.1}}],
+         "nodes": [{"children": [1, 4], "translation": [1, 2, 3]},
+                   {"mesh": 0, "scale": [2, 2, 2], "rotation": [0, 0, 0.70710678, 0.70710678], "children": [2]},
+                   {"mesh": 1},                                       # below a mesh node: never reached
+                   {"mesh": 1, "matrix": col_major},                  # a second root
+                   {"camera": 0, "children": [5]},                    # camera node: skipped with its subtree
+                   {"mesh": 1}],
+         "scenes": [{"nodes": [3]}], "scene": 0}                      # ignored: roots are the nodes without a parent
+    (tmp_path / "s.gltf").write_text(json.dumps(g))
+    return str(tmp_path / "s.gltf"), pos
+
+
+def test_gltf_traversal_transforms_and_materials(tmp_path):
+    path, pos = _gltf_fixture(tmp_path)
+    m = loaders.load_gltf(path)
+    assert len(m.meshes) == 2 and m.num_triangles == 3
+    a, b = m.meshes
+    # node 1 under node 0: T(1,2,3) * R_z(90 deg) * S(2): (x, y, 0) -> (1 - 2y, 2 + 2x, 3)
+    want = np.stack([1 - 2 * pos[:, 1], 2 + 2 * pos[:, 0], np.full(4, 3.0)], 1)
+    assert np.allclose(a.vertex, want, atol=1e-5) and a.vertex.dtype == np.float32
+    assert a.index.tolist() == [[0, 1, 2], [2, 1, 3]] and a.index.dtype == np.uint32
+    assert a.texcoord is not None and a.texcoord.shape == (4, 2) and a.texture_id == -1
+    assert (a.material.color.x, a.material.color.y, a.material.color.z) == pytest.approx((0.2, 0.4, 0.6))
+    assert a.material.roughness == pytest.approx(0.3) and a.material.metallic == pytest.approx(0.1)
+    assert (a.material.emission.x, a.material.emission.y, a.material.emission.z) == (1.0, 2.0, 3.0)
+    # the second root: column-major matrix = translation; no indices: one triangle from the first three vertices
+    assert np.array_equal(b.vertex, pos + np.float32([10, 20, 30])) and b.index.tolist() == [[0, 1, 2]]
+    assert b.texcoord is None and b.material.roughness == 1.0 and b.material.metallic == 1.0      # glTF defaults
+    assert (b.material.emission.x, b.material.emission.y, b.material.emission.z) == (0.0, 0.0, 0.0)
+    # everything else of Material() keeps the constructor defaults (as loadOBJ does)
+    from fovpathtracing_optixcodelatest_amd.abi import Material
+    d = Material.reference_default()
+    assert b.material.transmission == d.transmission and b.material.specular == d.specular and b.material.eta == d.eta
+
+
+def test_gltf_model_packs_for_the_c_abi(tmp_path):
+    from fovpathtracing_optixcodelatest_amd import scenes
+    path, _ = _gltf_fixture(tmp_path)
+    md, n, td, nt, keep = scenes.pack_model(loaders.load_gltf(path))
+    assert n == 2 and nt == 0 and md[0].num_triangles == 2 and md[1].num_triangles == 1 and md[0].texture_id == -1
