@@ -63,6 +63,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--advance-subframe", action="store_true",
+                    help="let render() advance subframe_index from frame to frame (new P-pass seeds every frame) instead of "
+                         "resetting it to 0 as the shipped application does (main.cpp:402-407)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,7 +136,8 @@ def main():
                 pending[k].wait()                              # the library's stream waits for it (device side)
                 pending[k] = None
             # the shipped app resets subframe_index to 0 before every render() (main.cpp:402-407)
-            r.launchParams.frame.subframe_index = 0
+            if not args.advance_subframe:
+                r.launchParams.frame.subframe_index = 0
             r.launchParams.frame.frame_buffer = frames[k].data_ptr()
             r.render_async()
             if world > 1 and not sync_gather:                  # RCCL waits for the frame, then reduces beside frame k+1
@@ -286,7 +290,8 @@ def main():
         # the timed frames are parity frames too: the oracle just rendered the same frame
         import numpy as np
         gpu_px = last_frame_host.numpy().view(np.uint32).reshape(H, W)
-        out["parity_vs_oracle_rgba8_mismatch"] = int((gpu_px != F.frame).sum())
+        if not args.advance_subframe:                        # (with advancing seeds the last timed frame is not frame 0)
+            out["parity_vs_oracle_rgba8_mismatch"] = int((gpu_px != F.frame).sum())
 
     if world > 1 and rank == 0 and os.environ.get("FOVPT_BENCH_CHECK") == "1":
         # the gathered frame on rank 0 must be the unsharded frame, bit for bit
