@@ -361,3 +361,27 @@ def test_gltf_loaded_scene(oracle, tmp_path):
     assert _bits_equal(r.downloadAccum(), F.accum) and np.array_equal(r.downloadPixels(), F.frame)
     assert int((r.downloadPixels() != 0).sum()) > 0.5 * size[0] * size[1]
     r.close()
+
+
+def test_small_geometry_seen_from_far_away(oracle):
+    """The box test of the traversal must stay conservative where its rounding errors are largest relative
+    to the boxes: centimetre triangles around the origin and far off it, camera 1500 units away, narrow
+    field of view.  A missed box would show up as a pixel that differs from the oracle."""
+    rng = np.random.default_rng(11)
+    n = 3000
+    centre = np.concatenate([rng.uniform(-0.6, 0.6, (n // 2, 3)), rng.uniform(-0.6, 0.6, (n - n // 2, 3)) + np.float32([900.0, -700.0, 0.0])])
+    tri = centre[:, None, :] + rng.uniform(-0.02, 0.02, (n, 3, 3))
+    verts = tri.reshape(-1, 3).astype(np.float32)
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    model = scenes.Model(meshes=[scenes.TriangleMesh(vertex=verts, index=idx, material=scenes.matte((0.8, 0.7, 0.6), emission=(0.5, 0.5, 0.5)))])
+    size, cfg = (192, 128), cfg_uniform(2, max_depth=3)
+    for eye, lookat, fov in (((0.0, 0.0, 1500.0), (0.0, 0.0, 0.0), 0.055), ((900.0, -700.0, -1200.0), (900.0, -700.0, 0.0), 0.07)):
+        cam = dict(eye=eye, lookat=lookat, up=(0.0, 1.0, 0.0), fovy=fov)
+        r = make_gpu(model, scenes.ambient_probe(32, 16, 1.0), cam, size, cfg)
+        r.render()
+        S, F = make_oracle(oracle, model, scenes.ambient_probe(32, 16, 1.0), cam, size)
+        oracle.render(S, F, cfg)
+        assert _bits_equal(r.downloadAccum(), F.accum) and np.array_equal(r.downloadPixels(), F.frame)
+        covered = int((F.accum[..., :3].sum(-1) > 1.0).sum())
+        assert covered > 0.15 * size[0] * size[1]
+        r.close()
