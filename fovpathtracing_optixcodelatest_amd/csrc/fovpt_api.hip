@@ -36,14 +36,14 @@ struct EventPair { hipEvent_t a, b; int kind; };   // kind: 0 gen, 1 trace, 2 sh
 }  // namespace
 
 struct StateSet {
-    DevBuf s_ray_o, s_ray_d, s_thr, s_rng, s_hit, s_rad, s_alpha, s_backplate, s_guide_n, s_guide_a;
-    DevBuf q_a, q_b, sq_o[2], sq_d[2], sq_vis[2], sq_occ[2], counters;
+    DevBuf s_thr, s_rng, s_hit, s_rad, s_alpha, s_backplate, s_guide_n, s_guide_a;
+    DevBuf q_o[2], q_d[2], sq_o[2], sq_d[2], sq_vis[2], sq_occ[2], counters;     // q_*: the two radiance-ray queues (ping-pong)
     hipEvent_t ev_shade[FOVPT_MAX_ITERS + 1] = {};
     hipEvent_t ev_shadow[FOVPT_MAX_ITERS + 1] = {};
     hipEvent_t ev_done = nullptr;          // recorded after the resolve of the last job that used this set
     bool used = false;
-    DevBuf* all[27] = {&s_ray_o, &s_ray_d, &s_thr, &s_rng, &s_hit, &s_rad, &s_alpha, &s_backplate, &s_guide_n, &s_guide_a,
-                       &q_a, &q_b, &sq_o[0], &sq_d[0], &sq_vis[0], &sq_occ[0], &sq_o[1], &sq_d[1], &sq_vis[1], &sq_occ[1], &counters,
+    DevBuf* all[27] = {&q_o[0], &q_d[0], &s_thr, &s_rng, &s_hit, &s_rad, &s_alpha, &s_backplate, &s_guide_n, &s_guide_a,
+                       &q_o[1], &q_d[1], &sq_o[0], &sq_d[0], &sq_vis[0], &sq_occ[0], &sq_o[1], &sq_d[1], &sq_vis[1], &sq_occ[1], &counters,
                        nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
@@ -161,7 +161,6 @@ void free_scene(fovpt_ctx* c)
 int ensure_state(fovpt_ctx* c, StateSet& S, size_t slots, size_t launches)
 {
     const size_t v = 16;
-    HIPCHK(c, S.s_ray_o.reserve(slots * v)); HIPCHK(c, S.s_ray_d.reserve(slots * v));
     HIPCHK(c, S.s_thr.reserve(slots * v)); HIPCHK(c, S.s_rng.reserve(slots * v));
     HIPCHK(c, S.s_hit.reserve(slots * v)); HIPCHK(c, S.s_alpha.reserve(slots * v));
     HIPCHK(c, S.s_rad.reserve(slots * v * (size_t)c->cfg.max_depth));
@@ -171,8 +170,8 @@ int ensure_state(fovpt_ctx* c, StateSet& S, size_t slots, size_t launches)
     // the shadow queue is double-buffered because bounce it's occlusion rays may still be in flight
     // on the shadow stream while bounce it+1 is being shaded
     const size_t qn = slots * FOVPT_SHARDS;
-    HIPCHK(c, S.q_a.reserve(qn * 4)); HIPCHK(c, S.q_b.reserve(qn * 4));
     for (int k = 0; k < 2; k++) {
+        HIPCHK(c, S.q_o[k].reserve(qn * v)); HIPCHK(c, S.q_d[k].reserve(qn * v));
         HIPCHK(c, S.sq_o[k].reserve(qn * v)); HIPCHK(c, S.sq_d[k].reserve(qn * v));
         HIPCHK(c, S.sq_vis[k].reserve(qn * v)); HIPCHK(c, S.sq_occ[k].reserve(qn * v));
     }
@@ -289,7 +288,7 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     S.used = true;
 
     PathState ps;
-    ps.ray_o = (float4*)S.s_ray_o.p; ps.ray_d = (float4*)S.s_ray_d.p; ps.thr = (float4*)S.s_thr.p;
+    ps.thr = (float4*)S.s_thr.p;
     ps.rng = (uint4*)S.s_rng.p; ps.hit = (float4*)S.s_hit.p; ps.rad = (float4*)S.s_rad.p; ps.stride = (size_t)c->cfg.max_depth;
     ps.alpha = (float4*)S.s_alpha.p; ps.backplate = (float4*)S.s_backplate.p;
     ps.guide_n = c->cfg.write_guides ? (float4*)S.s_guide_n.p : nullptr;
@@ -304,8 +303,9 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     sc.meshes = (const MeshDev*)c->meshes.p; sc.textures = (const TexDev*)c->textures.p;
     sc.num_tris = c->num_tris; sc.any_catcher = c->any_catcher;
     Counters* cnt = (Counters*)S.counters.p;
-    uint32_t* qa = (uint32_t*)S.q_a.p;
-    uint32_t* qb = (uint32_t*)S.q_b.p;
+    RayQueue qa, qb;
+    qa.o = (float4*)S.q_o[0].p; qa.d = (float4*)S.q_d[0].p;
+    qb.o = (float4*)S.q_o[1].p; qb.d = (float4*)S.q_d[1].p;
 
     // (the queue counters are zero: at allocation, and again by the resolve of the set's previous job)
     const int grid = c->grid;
@@ -329,7 +329,7 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
         { Timed t(c, 3, ss); fovpt_launch_traverse(ss, sc, ps, qb, sq[it & 1], cap, cnt, -1, it, c->grid_shadow); }
         HIPCHK(c, hipEventRecord(S.ev_shadow[it], ss));
         if (it + 1 < iters) { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qb, sq[0], cap, cnt, it + 1, -1, grid); }
-        uint32_t* tmp = qa; qa = qb; qb = tmp;
+        const RayQueue tmp = qa; qa = qb; qb = tmp;
     }
     { Timed t(c, 4, ss); fovpt_launch_resolve(ss, fd, ps, cnt); }
     HIPCHK(c, hipEventRecord(S.ev_done, ss));
@@ -856,7 +856,7 @@ int fovpt_debug_buffer(fovpt_ctx* c, const char* name, void** ptr, size_t* bytes
     StateSet& S = c->set[(c->jobs + 1u) & 1u];            // the set the most recent job used
     struct { const char* n; DevBuf* b; } tab[] = {
         {"sq_o", &S.sq_o[1]}, {"sq_d", &S.sq_d[1]}, {"sq_vis", &S.sq_vis[1]}, {"sq_occ", &S.sq_occ[1]}, {"counters", &S.counters},
-        {"hit", &S.s_hit}, {"queue_a", &S.q_a}, {"queue_b", &S.q_b}, {"ray_o", &S.s_ray_o}, {"ray_d", &S.s_ray_d},
+        {"hit", &S.s_hit}, {"queue_a_o", &S.q_o[0]}, {"queue_a_d", &S.q_d[0]}, {"queue_b_o", &S.q_o[1]}, {"queue_b_d", &S.q_d[1]},
     };
     for (auto& t : tab)
         if (strcmp(t.n, name) == 0) { *ptr = t.b->p; *bytes = t.b->bytes; return FOVPT_OK; }

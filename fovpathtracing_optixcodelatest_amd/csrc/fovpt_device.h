@@ -104,9 +104,15 @@ struct FrameDev {
 };
 
 // Per-sample-slot path state (SoA, 16-B vectors so every access is one dwordx4).
+// A radiance-ray queue holds the RAYS, not slot numbers: entry = origin.xyz + sample slot (bits of .w),
+// direction.xyz.  Sharded like every queue (FOVPT_SHARDS regions of `cap` entries).  A traversal or shading
+// wave reads 16 / 64 consecutive entries with coalesced loads and no indirection.
+struct RayQueue {
+    float4* o;
+    float4* d;
+};
+
 struct PathState {
-    float4* ray_o;      // origin.xyz, unused
-    float4* ray_d;      // direction.xyz, unused
     float4* thr;        // pathThroughput.xyz, rayEta
     uint4* rng;         // Random.seed1, Random.seed2, stateFlags (DONE 1, SECONDARY 2, ALPHA_ONE 4) | depth << 8, unused
     float4* hit;        // t, u, v, tri position in leaf order as bits (0xffffffff = miss)
@@ -162,12 +168,12 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
                             BvhBuildResult* out, char* err, size_t errlen);
 
 // cap = shard capacity (in items) of the radiance queues and of the shadow queue.
-void fovpt_launch_generate(hipStream_t st, const FrameDev& fd, PathState ps, uint32_t* queue0, uint32_t cap, Counters* cnt, uint32_t total_slots, int grid);
+void fovpt_launch_generate(hipStream_t st, const FrameDev& fd, PathState ps, RayQueue queue0, uint32_t cap, Counters* cnt, uint32_t total_slots, int grid);
 // One launch that traces the shadow queue of iteration it_shadow (if >= 0) and the radiance queue of
 // iteration it_closest (if >= 0).
-void fovpt_launch_traverse(hipStream_t st, SceneView sc, PathState ps, const uint32_t* queue, ShadowQueue sq, uint32_t cap,
+void fovpt_launch_traverse(hipStream_t st, SceneView sc, PathState ps, RayQueue queue, ShadowQueue sq, uint32_t cap,
                            Counters* cnt, int it_closest, int it_shadow, int grid);
-void fovpt_launch_shade(hipStream_t st, const FrameDev& fd, SceneView sc, PathState ps, const uint32_t* queue_in, uint32_t* queue_out,
+void fovpt_launch_shade(hipStream_t st, const FrameDev& fd, SceneView sc, PathState ps, RayQueue queue_in, RayQueue queue_out,
                         ShadowQueue sq, uint32_t cap, Counters* cnt, int depth, int grid);
 void fovpt_launch_resolve(hipStream_t st, const FrameDev& fd, PathState ps, Counters* cnt);
 void fovpt_launch_build_guide(hipStream_t st, const float* cdf, int n, int segments, uint32_t* guide);

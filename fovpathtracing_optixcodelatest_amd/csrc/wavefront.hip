@@ -516,7 +516,7 @@ __device__ inline bool ring_alive(const FrameDev& fd, const PassDev& P, uint32_t
 }
 
 // ---- generate ----------------------------------------------------------------------------
-__global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, PathState ps, uint32_t* __restrict__ queue0, uint32_t cap,
+__global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, PathState ps, RayQueue queue0, uint32_t cap,
                                                           Counters* __restrict__ cnt, uint32_t total_slots)
 {
     __shared__ uint32_t s_scratch[6];
@@ -525,6 +525,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, Pat
         bool live = slot < total_slots;
         int p = 0;
         uint32_t lx = 0, ly = 0, s = 0, ix = 0, iy = 0;
+        V3 ray_dir = v3(0.f);
         if (live) {
             while (p + 1 < fd.npass && slot >= fd.pass[p + 1].slot_base) p++;
             const PassDev& P = fd.pass[p];
@@ -549,8 +550,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, Pat
             const float dy = 2.0f * (((float)iy + jy) / (float)fd.h) - 1.0f;
             const V3 U = v3(fd.U[0], fd.U[1], fd.U[2]), V = v3(fd.V[0], fd.V[1], fd.V[2]), W = v3(fd.W[0], fd.W[1], fd.W[2]);
             const V3 dir = normalize(dx * U + dy * V + W);                      // :491
-            ps.ray_o[slot] = make_float4(fd.eye[0], fd.eye[1], fd.eye[2], 0.f);
-            ps.ray_d[slot] = f4(dir, 0.f);
+            ray_dir = dir;
             ps.rng[slot] = make_uint4(rng.s1, rng.s2, 0u, 0u);                  // stateFlags 0, depth 0
             // Nothing else is initialised: pathThroughput / rayEta are (1,1,1) / 1 until the first shaded hit
             // (k_shade), the radiance cells [0, depth) and alpha are written exactly once before resolve
@@ -563,7 +563,10 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, Pat
             }
         }
         const uint32_t pos = block_append(cnt, FOVPT_CNT_Q(0), cap, live, s_scratch);
-        if (live) queue0[pos] = slot;
+        if (live) {
+            queue0.o[pos] = make_float4(fd.eye[0], fd.eye[1], fd.eye[2], __uint_as_float(slot));
+            queue0.d[pos] = f4(ray_dir, 0.f);
+        }
     }
 }
 
@@ -915,7 +918,7 @@ __device__ inline void traverse_shadow_pool(const SceneView& sc, const PathState
 // iteration it_closest, one ray per QUAD of lanes (16 rays per wave).
 // (Dynamic work fetching with a global counter and per-lane replacement was measured and rejected: with
 // so few rays per resident lane per launch a returning atomic per wave costs more than the imbalance.)
-__global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneView sc, PathState ps, const uint32_t* __restrict__ queue, ShadowQueue sq,
+__global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneView sc, PathState ps, RayQueue queue, ShadowQueue sq,
                                                                          uint32_t cap, Counters* __restrict__ cnt, int it_closest, int it_shadow)
 {
     __shared__ int s_stack[(FOVPT_STACK + 4) * FOVPT_QUADS_PER_BLOCK];  // + the end marker and three rows of slack above the top
@@ -944,12 +947,14 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
         const uint32_t i0 = __builtin_amdgcn_readfirstlane(i - ((threadIdx.x & 63u) >> 2));      // the wave's 16 rays: i0 .. i0+15
         RayT r;
         QuadTrav T;
-        const uint32_t slot = queue[mq.phys16(i, i0, cap)];
-        ray_setup(r, ps.ray_o[slot], ps.ray_d[slot]);
+        const uint32_t ph = mq.phys16(i, i0, cap);
+        const float4 o = queue.o[ph], d = queue.d[ph];
+        const uint32_t slot = __float_as_uint(o.w);
+        ray_setup(r, o, d);
         traverse_quad(sc, r, stack, q, T, cnt->diag[0]);
         store_hit(ps, slot, T);
 #if FOVPT_V_STEPSTAT
-        if (q.j == 0) ((uint32_t*)&ps.ray_d[slot])[3] = T.steps;         // tools/raystat.py
+        if (q.j == 0) ((uint32_t*)&queue.d[ph])[3] = T.steps;            // tools/raystat.py
 #endif
     }
 }
@@ -1003,7 +1008,7 @@ __device__ inline float4 tex2d(const TexDev& T, float u, float v)
 #define FOVPT_V_SHADEWAVES 1
 #endif
 __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const FrameDev fd, SceneView sc, PathState ps,
-                                                       const uint32_t* __restrict__ queue_in, uint32_t* __restrict__ queue_out,
+                                                       RayQueue queue_in, RayQueue queue_out,
                                                        ShadowQueue sq, uint32_t cap, Counters* __restrict__ cnt, int depth_iter)
 {
     __shared__ uint32_t s_scratch[10];
@@ -1014,10 +1019,13 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
     for (uint32_t i = blockIdx.x * FOVPT_BLOCK + threadIdx.x; i < nround; i += gridDim.x * FOVPT_BLOCK) {
         bool want_shadow = false, want_next = false;
         uint32_t slot = 0;
+        V3 next_o = v3(0.f), next_d = v3(0.f);
         float4 sh_o, sh_d, sh_vis, sh_occ;
         sh_o = sh_d = sh_vis = sh_occ = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < n) {
-            slot = queue_in[mq.phys(i, cap)];
+            const uint32_t ph = mq.phys(i, cap);
+            const float4 o4 = queue_in.o[ph], d4 = queue_in.d[ph];
+            slot = __float_as_uint(o4.w);
             const float4 hit = ps.hit[slot];
             const uint32_t tpos = __float_as_uint(hit.w);
             uint4 rs = ps.rng[slot];
@@ -1027,7 +1035,6 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
                 // __miss__radiance :253-282: DONE; nothing is added for this segment (:515 breaks first)
                 flags |= FLAG_DONE;
             } else {
-                const float4 o4 = ps.ray_o[slot], d4 = ps.ray_d[slot];
                 const V3 ray_o = v3(o4), ray_dir = v3(d4);
                 const TriRec T = load_tri_off(sc.tris, tpos << 4);            // tpos: offset in 16-byte units
                 const MeshDev M = sc.meshes[T.mesh];
@@ -1041,7 +1048,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
                 if (catcher && (flags & FLAG_SECONDARY)) {
                     // :646-651: pass straight through, depth unchanged after the loop's ++depth;
                     // the loop adds prd.radiance == 0 to direct/indirect, which changes nothing
-                    ps.ray_o[slot] = f4(P, 0.f);
+                    next_o = P; next_d = ray_dir;
                     want_next = true;
                 } else if (depth >= fd.max_depth) {
                     // the reference's discarded last segment (:515).  It is only traced here when the
@@ -1145,8 +1152,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
                         // away (:515).  Without a shadow catcher in the scene that segment cannot
                         // change anything (alpha is already 1), so it is not traced.
                         if (depth < fd.max_depth || sc.any_catcher) {
-                            ps.ray_o[slot] = f4(P, 0.f);
-                            ps.ray_d[slot] = f4(bsdfDir, 0.f);
+                            next_o = P; next_d = bsdfDir;
                             ps.thr[slot] = f4(thr, rayEta);
                             want_next = true;
                         }
@@ -1161,7 +1167,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
         uint32_t spos, qpos;
         block_append2(cnt, FOVPT_CNT_SQ(depth_iter), want_shadow, FOVPT_CNT_Q(depth_iter + 1), want_next, cap, s_scratch, spos, qpos);
         if (want_shadow) { sq.o[spos] = sh_o; sq.d[spos] = sh_d; sq.val_vis[spos] = sh_vis; sq.val_occ[spos] = sh_occ; }
-        if (want_next) queue_out[qpos] = slot;
+        if (want_next) { queue_out.o[qpos] = f4(next_o, __uint_as_float(slot)); queue_out.d[qpos] = f4(next_d, 0.f); }
     }
 }
 
@@ -1432,16 +1438,16 @@ __global__ void k_math(int op, const float* a, const float* b, float* out, size_
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
-void fovpt_launch_generate(hipStream_t st, const FrameDev& fd, PathState ps, uint32_t* queue0, uint32_t cap, Counters* cnt, uint32_t total_slots, int grid)
+void fovpt_launch_generate(hipStream_t st, const FrameDev& fd, PathState ps, RayQueue queue0, uint32_t cap, Counters* cnt, uint32_t total_slots, int grid)
 {
     hipLaunchKernelGGL(k_generate, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, ps, queue0, cap, cnt, total_slots);
 }
-void fovpt_launch_traverse(hipStream_t st, SceneView sc, PathState ps, const uint32_t* queue, ShadowQueue sq, uint32_t cap,
+void fovpt_launch_traverse(hipStream_t st, SceneView sc, PathState ps, RayQueue queue, ShadowQueue sq, uint32_t cap,
                            Counters* cnt, int it_closest, int it_shadow, int grid)
 {
     hipLaunchKernelGGL(k_traverse, dim3(grid), dim3(FOVPT_BLOCK), 0, st, sc, ps, queue, sq, cap, cnt, it_closest, it_shadow);
 }
-void fovpt_launch_shade(hipStream_t st, const FrameDev& fd, SceneView sc, PathState ps, const uint32_t* queue_in, uint32_t* queue_out,
+void fovpt_launch_shade(hipStream_t st, const FrameDev& fd, SceneView sc, PathState ps, RayQueue queue_in, RayQueue queue_out,
                         ShadowQueue sq, uint32_t cap, Counters* cnt, int depth, int grid)
 {
     hipLaunchKernelGGL(k_shade, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, sc, ps, queue_in, queue_out, sq, cap, cnt, depth);

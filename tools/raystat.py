@@ -27,12 +27,12 @@ raw = buf("counters", np.uint8)
 stride = (raw.size - 24 - 64) // 8 // 4
 sh = raw[:8 * stride * 4].view(np.uint32).reshape(8, stride)
 n1 = sh[:, 1]                             # radiance queue sizes of iteration 1, per shard
-qb = buf("queue_b", np.uint32); cap = qb.size // 8
-slots = np.concatenate([qb[s * cap:s * cap + n1[s]] for s in range(8)])
-rd = buf("ray_d", np.float32).reshape(-1, 4); ro = buf("ray_o", np.float32).reshape(-1, 4)
-st = rd[slots, 3].view(np.uint32)
+qo = buf("queue_b_o", np.float32).reshape(-1, 4); qd = buf("queue_b_d", np.float32).reshape(-1, 4); cap = qo.shape[0] // 8
+sel = np.concatenate([np.arange(s * cap, s * cap + n1[s]) for s in range(8)])
+slots = qo[sel, 3].view(np.uint32)
+st = qd[sel, 3].view(np.uint32)                  # node | leaf << 16 steps, written by the STEPSTAT traversal
 steps = (st & 0xffff) + 2.7 * (st >> 16)         # a leaf step costs about 2.7 node steps
-d = rd[slots, :3]; o = ro[slots, :3]
+d = qd[sel, :3]; o = qo[sel, :3]
 print("bounce-1 rays:", slots.size, "mean cost %.1f" % steps.mean(), "node %.1f leaf %.2f" % ((st & 0xffff).mean(), (st >> 16).mean()))
 def wave_cost(order, label):
     s = steps[order]
