@@ -872,8 +872,8 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
 // its ray takes the next one of the pool as soon as FOVPT_REFILL quads of the wave are idle (all of them
 // at the end), so the wave does not wait for its longest ray after every 16 -- occlusion rays end after
 // very different numbers of steps (SIMD utilisation 36 % with static rounds).  The pool is private to
-// the wave: no atomics.  (For closest-hit rays the same scheme was measured 14 % slower: a refill stalls
-// the whole wave behind two dependent loads, queue -> slot -> ray.)
+// the wave: no atomics.  (For closest-hit rays the same scheme was measured 10 % slower: the divergent
+// refill -- merge and store the hit, fetch, set up -- costs more than their better lane use returns.)
 #define FOVPT_REFILL 6
 __device__ inline void traverse_shadow_pool(const SceneView& sc, const PathState& ps, const ShadowQueue& sq, const ShardMap& map, uint32_t cap,
                                             uint32_t first, uint32_t end, int* __restrict__ stack, const QuadLane& q, unsigned long long* diag)
