@@ -74,7 +74,7 @@ struct fovpt_ctx {
     StateSet set[2];
     unsigned jobs = 0;                     // jobs issued so far; job j uses set[j & 1]
     int grid = 2048, grid_shadow = 1024;
-    uint64_t slot_budget = 16ull << 20;    // sample slots per wavefront job (~1.3 KB of state and queues each)
+    uint64_t slot_budget = 64ull << 20;    // sample slots per wavefront job (~330 B of state and queues each, two sets)
     // stats
     fovpt_stats stats;
     std::vector<EventPair> pending;
@@ -158,6 +158,12 @@ void free_scene(fovpt_ctx* c)
     c->has_scene = false;
 }
 
+// A queue shard receives the appends of the blocks whose index is congruent to it modulo FOVPT_SHARDS.  The
+// producing kernels walk their index space in 256-wide block iterations m = 0, 1, 2, ... with a grid that is
+// a multiple of FOVPT_SHARDS, so shard s gets the iterations m = s (mod 8): at most ceil(M / 8) + 1 of them,
+// each appending at most 256 entries.  Nothing can overflow a shard of slots / 8 + 512 entries.
+uint32_t shard_capacity(size_t slots) { return (uint32_t)(slots / FOVPT_SHARDS + 512); }
+
 int ensure_state(fovpt_ctx* c, StateSet& S, size_t slots, size_t launches)
 {
     const size_t v = 16;
@@ -166,10 +172,10 @@ int ensure_state(fovpt_ctx* c, StateSet& S, size_t slots, size_t launches)
     HIPCHK(c, S.s_rad.reserve(slots * v * (size_t)c->cfg.max_depth));
     HIPCHK(c, S.s_backplate.reserve(launches * v));
     if (c->cfg.write_guides) { HIPCHK(c, S.s_guide_n.reserve(slots * v)); HIPCHK(c, S.s_guide_a.reserve(slots * v)); }
-    // sharded queues: FOVPT_SHARDS regions of `slots` entries each (memory is laid out for 288 GB);
+    // sharded queues: FOVPT_SHARDS regions of shard_capacity(slots) entries each;
     // the shadow queue is double-buffered because bounce it's occlusion rays may still be in flight
     // on the shadow stream while bounce it+1 is being shaded
-    const size_t qn = slots * FOVPT_SHARDS;
+    const size_t qn = (size_t)shard_capacity(slots) * FOVPT_SHARDS;
     for (int k = 0; k < 2; k++) {
         HIPCHK(c, S.q_o[k].reserve(qn * v)); HIPCHK(c, S.q_d[k].reserve(qn * v));
         HIPCHK(c, S.sq_o[k].reserve(qn * v)); HIPCHK(c, S.sq_d[k].reserve(qn * v));
@@ -249,7 +255,7 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
         launches += (uint64_t)P.gw * rows;
         fd.pass[p] = P;
     }
-    if (slots * FOVPT_SHARDS >= (1ull << 32)) return fail(c, FOVPT_E_INVALID, "launch too large: %llu sample slots", (unsigned long long)slots);
+    if (slots >= (1ull << 31)) return fail(c, FOVPT_E_INVALID, "launch too large: %llu sample slots", (unsigned long long)slots);
     fd.npass = npass;
     fd.w = lp->frame.size.x; fd.h = lp->frame.size.y;
     fd.cx = lp->frame.c.x; fd.cy = lp->frame.c.y;
@@ -309,7 +315,7 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
 
     // (the queue counters are zero: at allocation, and again by the resolve of the set's previous job)
     const int grid = c->grid;
-    const uint32_t cap = (uint32_t)slots;              // shard capacity: any shard may hold everything
+    const uint32_t cap = shard_capacity((size_t)slots);
     { Timed t(c, 0); fovpt_launch_generate(st, fd, ps, qa, cap, cnt, (uint32_t)slots, grid); }
     // iterations: depth 0 .. max_depth-1, plus the reference's discarded segment and shadow-catcher
     // pass-throughs (which do not advance depth) when the scene holds a catcher
@@ -372,10 +378,11 @@ int fovpt_create(fovpt_ctx** out, int device)
     memset(&c->stats, 0, sizeof(c->stats));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
-    c->grid = c->num_cus * 8;                 // 8 blocks of 256 = 32 waves per CU, grid-stride over the queues
+    c->grid = c->num_cus * 8;                 // 8 blocks of 256 = 32 waves per CU, grid-stride over the queues; a multiple of FOVPT_SHARDS
     c->grid_shadow = c->num_cus * 6;          // occlusion launches (measured best of 2..8 with per-wave ray pools)
     if (const char* g = getenv("FOVPT_GRID")) { const int v = atoi(g); if (v > 0 && v <= 16) c->grid = c->num_cus * v; }                 // tuning: blocks per CU
     if (const char* g = getenv("FOVPT_GRID_SHADOW")) { const int v = atoi(g); if (v > 0 && v <= 16) c->grid_shadow = c->num_cus * v; }   // tuning: blocks per CU
+    c->grid = (c->grid + FOVPT_SHARDS - 1) / FOVPT_SHARDS * FOVPT_SHARDS;      // shard_capacity() relies on it
     if (const char* sb = getenv("FOVPT_SLOT_BUDGET")) { const long long v = atoll(sb); if (v > 0) c->slot_budget = (uint64_t)v; }   // tests: force chunking
     // the main chain is the critical path: give it the higher priority so occlusion waves only fill gaps
     int prio_lo = 0, prio_hi = 0;
