@@ -573,33 +573,10 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, Pat
 // ---- traversal ---------------------------------------------------------------------------
 // Quad-cooperative traversal: FOUR adjacent lanes share one ray.  On a wide node lane j tests child j
 // (so a node visit is one box test deep instead of four), on a leaf lane j tests triangle j; the four
-// results meet through DPP quad permutes (register-to-register, no LDS).  A wave thus carries 16
-// rays, each step is ~3x shorter than with one lane per ray, and divergence is between 16 rays
-// instead of 64.  With the single-thread latency of a CU (~1 us per dependent traversal step at
-// one lane per ray) this is what bounds a frame: every bounce ends with the longest ray of its launch.
-template <int K>
-__device__ inline float quad_bcast(float v)        // value of lane K of this lane's quad
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), K * 0x55, 0xf, 0xf, false));
-}
-template <int K>
-__device__ inline int quad_bcast(int v)
-{
-    return __builtin_amdgcn_update_dpp(0, v, K * 0x55, 0xf, 0xf, false);
-}
-__device__ inline float quad_min(float v)
-{
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false)));   // [1,0,3,2]
-    v = fminf(v, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false)));   // [2,3,0,1]
-    return v;
-}
-__device__ inline int quad_or(int v)
-{
-    v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
-    v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
-    return v;
-}
-
+// results meet through the wave ballot and DPP quad permutes (register to register).  A wave thus
+// carries 16 rays, each step is ~3x shorter than with one lane per ray, and divergence is between 16
+// rays instead of 64.  The vector ALU is what a step costs, so the steps are
+// written instruction by instruction.
 struct RayT {
     float ox, oy, oz, dx, dy, dz;
     float ix, iy, iz;          // safe reciprocal direction for the box test
@@ -638,36 +615,8 @@ __device__ inline bool box_hit(const RayT& r, float lx, float ly, float lz, floa
     return t0 <= t1 * 1.000001f;
 }
 
-// Moeller-Trumbore, identical operation order to the parity contract (oracle intersect_tri)
-__device__ inline bool tri_hit(const RayT& r, const TriRec& T, float& t, float& u, float& v, float& det)
-{
-    const V3 d = v3(r.dx, r.dy, r.dz);
-    const V3 e1 = v3(T.e1x, T.e1y, T.e1z), e2 = v3(T.e2x, T.e2y, T.e2z);
-    const V3 p = cross(d, e2);
-    det = dot(e1, p);
-    if (det == 0.0f) return false;
-    const float inv = 1.0f / det;
-    const V3 s = v3(r.ox, r.oy, r.oz) - v3(T.v0x, T.v0y, T.v0z);
-    u = dot(s, p) * inv;
-    if (!(u >= 0.0f && u <= 1.0f)) return false;
-    const V3 q = cross(s, e1);
-    v = dot(d, q) * inv;
-    if (!(v >= 0.0f && u + v <= 1.0f)) return false;
-    t = dot(e2, q) * inv;
-    return true;
-}
-
-__device__ inline TriRec load_tri(const TriRec* __restrict__ tris, uint32_t i)
-{
-    const float4* p = (const float4*)(tris + i);
-    const float4 a = p[0], b = p[1], c = p[2];
-    TriRec T;
-    T.v0x = a.x; T.v0y = a.y; T.v0z = a.z; T.e1x = a.w;
-    T.e1y = b.x; T.e1z = b.y; T.e2x = b.z; T.e2y = b.w;
-    T.e2z = c.x; T.prim = __float_as_uint(c.y); T.mesh = __float_as_uint(c.z); T.pad = 0;
-    return T;
-}
-
+// triangle records: Moeller-Trumbore on them is in leaf_step, in the operation order of the parity contract
+// (oracle intersect_tri)
 __device__ inline TriRec load_tri_off(const TriRec* __restrict__ tris, uint32_t byte_off)
 {
     const float4* p = (const float4*)((const char*)tris + byte_off);
