@@ -479,8 +479,6 @@ int fovpt_set_scene(fovpt_ctx* c, const fovpt_mesh_desc* meshes, int num_meshes,
     HIPCHK(c, hipMalloc(&d_mesh_of, mesh_of.size() * 4));
     HIPCHK(c, hipMemcpy(d_flat, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(d_mesh_of, mesh_of.data(), mesh_of.size() * 4, hipMemcpyHostToDevice));
-    HIPCHK(c, c->meshes.reserve(md.size() * sizeof(MeshDev)));
-    HIPCHK(c, hipMemcpy(c->meshes.p, md.data(), md.size() * sizeof(MeshDev), hipMemcpyHostToDevice));
     if (any_tc) {
         HIPCHK(c, c->tri_tc.reserve(tc.size() * 4));
         HIPCHK(c, hipMemcpy(c->tri_tc.p, tc.data(), tc.size() * 4, hipMemcpyHostToDevice));
@@ -499,6 +497,12 @@ int fovpt_set_scene(fovpt_ctx* c, const fovpt_mesh_desc* meshes, int num_meshes,
     }
     HIPCHK(c, c->textures.reserve(td.size() * sizeof(TexDev)));
     HIPCHK(c, hipMemcpy(c->textures.p, td.data(), td.size() * sizeof(TexDev), hipMemcpyHostToDevice));
+    for (int m = 0; m < num_meshes; m++) {
+        md[m].tex.px = nullptr; md[m].tex.w = md[m].tex.h = 0;
+        if (md[m].texture_id >= 0) md[m].tex = td[md[m].texture_id];
+    }
+    HIPCHK(c, c->meshes.reserve(md.size() * sizeof(MeshDev)));
+    HIPCHK(c, hipMemcpy(c->meshes.p, md.data(), md.size() * sizeof(MeshDev), hipMemcpyHostToDevice));
 
     hipEvent_t e0, e1;
     HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));

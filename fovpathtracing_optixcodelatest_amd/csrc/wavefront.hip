@@ -985,6 +985,13 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
                 flags |= FLAG_DONE;
             } else {
                 const V3 ray_o = v3(o4), ray_dir = v3(d4);
+                // ProbeSample is the first consumer of the path's random numbers on a shaded hit (:303-344) and
+                // depends on nothing else: its chain of dependent loads (guide tables, CDFs, texel) is started
+                // here, beside the chain hit -> triangle -> mesh -> texels.  Branches that do not shade drop it.
+                Rng rng_probe; rng_probe.s1 = rs.x; rng_probe.s2 = rs.y;
+                V3 wi, skyColor; float skyPdf;
+                probe_sample(fd.probe, fd.guide_x, fd.guide_y, fd.probe_row_mul, wi, skyColor, skyPdf, rng_probe);
+                const float4 thr_in = ps.thr[slot];                            // (unused garbage until the first shaded hit wrote it)
                 const TriRec T = load_tri_off(sc.tris, tpos << 4);            // tpos: offset in 16-byte units
                 const MeshDev M = sc.meshes[T.mesh];
                 const Mat& mat = M.material;
@@ -1006,10 +1013,10 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
                     flags |= FLAG_ALPHA_ONE | FLAG_DONE;
                 } else {
                     // pathThroughput (1,1,1) and rayEta 1 until the first shaded hit (:447-449)
-                    const float4 t4 = (flags & FLAG_SECONDARY) ? ps.thr[slot] : make_float4(1.f, 1.f, 1.f, 1.0f);
+                    const float4 t4 = (flags & FLAG_SECONDARY) ? thr_in : make_float4(1.f, 1.f, 1.f, 1.0f);
                     V3 thr = v3(t4);
                     float rayEta = t4.w;
-                    Rng rng; rng.s1 = rs.x; rng.s2 = rs.y;
+                    Rng rng = rng_probe;
                     V3 albedo = v3(mat.color);
                     if (M.texture_id >= 0 && M.has_texcoord) {                             // :655-670
                         const float2* tc = sc.tri_tc + (size_t)T.prim * 3;
@@ -1017,7 +1024,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
                         const float w0 = 1.f - hit.y - hit.z;
                         const float tcx = (w0 * t0.x + hit.y * t1.x) + hit.z * t2.x;
                         const float tcy = (w0 * t0.y + hit.y * t1.y) + hit.z * t2.y;
-                        albedo = v3(tex2d(sc.textures[M.texture_id], tcx, tcy));
+                        albedo = v3(tex2d(M.tex, tcx, tcy));
                     }
                     if (ps.guide_n && depth == 0 && (flags & FLAG_SECONDARY) == 0) {       // :509-512, :653-654
                         ps.guide_n[slot] = f4(N, 0.f);
@@ -1030,8 +1037,6 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
                         outEta = 1.0f;
                     // ---- SampleLights / SampleShadow :303-387 with the occlusion test deferred
                     const BsdfView view = bsdf_view(mat, albedo, rayEta, outEta, N, wo);
-                    V3 wi, skyColor; float skyPdf;
-                    probe_sample(fd.probe, fd.guide_x, fd.guide_y, fd.probe_row_mul, wi, skyColor, skyPdf, rng);
                     V3 sum_hit = v3(0.0f);        // value of `sum` on the branch that evaluates the BSDF
                     {
                         const float bsdfPdf = bsdf_pdf(mat, view, N, wo, wi);
