@@ -168,7 +168,8 @@ int ensure_state(fovpt_ctx* c, StateSet& S, size_t slots, size_t launches)
 {
     const size_t v = 16;
     HIPCHK(c, S.s_thr.reserve(slots * v)); HIPCHK(c, S.s_rng.reserve(slots * v));
-    HIPCHK(c, S.s_hit.reserve(slots * v)); HIPCHK(c, S.s_alpha.reserve(slots * v));
+    HIPCHK(c, S.s_hit.reserve((size_t)shard_capacity(slots) * FOVPT_SHARDS * v));      // indexed like the ray queues
+    HIPCHK(c, S.s_alpha.reserve(slots * v));
     HIPCHK(c, S.s_rad.reserve(slots * v * (size_t)c->cfg.max_depth));
     HIPCHK(c, S.s_backplate.reserve(launches * v));
     if (c->cfg.write_guides) { HIPCHK(c, S.s_guide_n.reserve(slots * v)); HIPCHK(c, S.s_guide_a.reserve(slots * v)); }

@@ -764,10 +764,11 @@ __device__ inline bool leaf_step(const SceneView& sc, const RayT& r, const QuadL
     return false;
 }
 
-// closest: store the hit record of the quad's ray.  Lowest t (bit patterns of t > 0 order like the
+// closest: store the hit record of the quad's ray AT THE RAY'S QUEUE POSITION (the shading kernel reads ray and
+// hit side by side).  Lowest t (bit patterns of t > 0 order like the
 // values), then lowest primitive id; lanes that tie on both hold the same triangle, hence the same
 // record: they all store it.
-__device__ inline void store_hit(const PathState& ps, uint32_t slot, const QuadTrav& T)
+__device__ inline void store_hit(const PathState& ps, uint32_t ph, const QuadTrav& T)
 {
     uint32_t mt = __float_as_uint(T.bt);
     mt = min(mt, quad_rot2(mt));
@@ -776,7 +777,7 @@ __device__ inline void store_hit(const PathState& ps, uint32_t slot, const QuadT
     uint32_t mp = cand ? T.bprim : 0xffffffffu;
     mp = min(mp, quad_rot2(mp));
     mp = min(mp, quad_rot1(mp));
-    if (cand && T.bprim == mp) ps.hit[slot] = make_float4(T.bt, T.bu, T.bv, __uint_as_float(T.bpos));
+    if (cand && T.bprim == mp) ps.hit[ph] = make_float4(T.bt, T.bu, T.bv, __uint_as_float(T.bpos));
 }
 // any-hit: the deferred NEE add of SampleLights / SampleShadow (deviceProgram.cu:323-341,367-385).
 // Every (slot, depth) cell has exactly one writer, so this is a plain store and the shadow rays of a
@@ -898,10 +899,9 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
         QuadTrav T;
         const uint32_t ph = mq.phys16(i, i0, cap);
         const float4 o = queue.o[ph], d = queue.d[ph];
-        const uint32_t slot = __float_as_uint(o.w);
         ray_setup(r, o, d);
         traverse_quad(sc, r, stack, q, T, cnt->diag[0]);
-        store_hit(ps, slot, T);
+        store_hit(ps, ph, T);
 #if FOVPT_V_STEPSTAT
         if (q.j == 0) ((uint32_t*)&queue.d[ph])[3] = T.steps;            // tools/raystat.py
 #endif
@@ -975,7 +975,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
             const uint32_t ph = mq.phys(i, cap);
             const float4 o4 = queue_in.o[ph], d4 = queue_in.d[ph];
             slot = __float_as_uint(o4.w);
-            const float4 hit = ps.hit[slot];
+            const float4 hit = ps.hit[ph];
             const uint32_t tpos = __float_as_uint(hit.w);
             uint4 rs = ps.rng[slot];
             uint32_t flags = rs.z & 0xffu;
