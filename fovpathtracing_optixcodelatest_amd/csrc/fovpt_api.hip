@@ -330,16 +330,15 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qa, sq[0], cap, cnt, 0, -1, grid); }
     for (int it = 0; it < iters; it++) {
         if (it >= 2) HIPCHK(c, hipStreamWaitEvent(st, S.ev_shadow[it - 2], 0));
-        { Timed t(c, 2); fovpt_launch_shade(st, fd, sc, ps, qa, qb, sq[it & 1], cap, cnt, it, grid); }
-        HIPCHK(c, hipEventRecord(S.ev_shade[it], st));
+        // the events ride on the kernels' own completion signals (hipExtLaunchKernel): a separate
+        // hipEventRecord would put a marker packet between shade(it) and closest(it+1), ~6 us on the critical path
+        { Timed t(c, 2); fovpt_launch_shade(st, fd, sc, ps, qa, qb, sq[it & 1], cap, cnt, it, grid, S.ev_shade[it]); }
         HIPCHK(c, hipStreamWaitEvent(ss, S.ev_shade[it], 0));
-        { Timed t(c, 3, ss); fovpt_launch_traverse(ss, sc, ps, qb, sq[it & 1], cap, cnt, -1, it, c->grid_shadow); }
-        HIPCHK(c, hipEventRecord(S.ev_shadow[it], ss));
+        { Timed t(c, 3, ss); fovpt_launch_traverse(ss, sc, ps, qb, sq[it & 1], cap, cnt, -1, it, c->grid_shadow, S.ev_shadow[it]); }
         if (it + 1 < iters) { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qb, sq[0], cap, cnt, it + 1, -1, grid); }
         const RayQueue tmp = qa; qa = qb; qb = tmp;
     }
-    { Timed t(c, 4, ss); fovpt_launch_resolve(ss, fd, ps, cnt); }
-    HIPCHK(c, hipEventRecord(S.ev_done, ss));
+    { Timed t(c, 4, ss); fovpt_launch_resolve(ss, fd, ps, cnt, S.ev_done); }
     HIPCHK(c, hipGetLastError());
     return FOVPT_OK;
 }
@@ -392,10 +391,10 @@ int fovpt_create(fovpt_ctx** out, int device)
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->shadow_stream, hipStreamDefault, prio_lo);
     for (StateSet& S : c->set) {
         for (int k = 0; k <= FOVPT_MAX_ITERS && e == hipSuccess; k++) {
-            e = hipEventCreateWithFlags(&S.ev_shade[k], hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&S.ev_shadow[k], hipEventDisableTiming);
+            e = hipEventCreateWithFlags(&S.ev_shade[k], hipEventDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&S.ev_shadow[k], hipEventDefault);
         }
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&S.ev_done, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&S.ev_done, hipEventDefault);
     }
     if (e != hipSuccess) { delete c; return fail(nullptr, FOVPT_E_DEVICE, "stream/event creation: %s", hipGetErrorString(e)); }
     *out = c;

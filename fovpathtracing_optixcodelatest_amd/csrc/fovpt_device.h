@@ -173,10 +173,10 @@ void fovpt_launch_generate(hipStream_t st, const FrameDev& fd, PathState ps, Ray
 // One launch that traces the shadow queue of iteration it_shadow (if >= 0) and the radiance queue of
 // iteration it_closest (if >= 0).
 void fovpt_launch_traverse(hipStream_t st, SceneView sc, PathState ps, RayQueue queue, ShadowQueue sq, uint32_t cap,
-                           Counters* cnt, int it_closest, int it_shadow, int grid);
+                           Counters* cnt, int it_closest, int it_shadow, int grid, hipEvent_t done = nullptr);
 void fovpt_launch_shade(hipStream_t st, const FrameDev& fd, SceneView sc, PathState ps, RayQueue queue_in, RayQueue queue_out,
-                        ShadowQueue sq, uint32_t cap, Counters* cnt, int depth, int grid);
-void fovpt_launch_resolve(hipStream_t st, const FrameDev& fd, PathState ps, Counters* cnt);
+                        ShadowQueue sq, uint32_t cap, Counters* cnt, int depth, int grid, hipEvent_t done = nullptr);
+void fovpt_launch_resolve(hipStream_t st, const FrameDev& fd, PathState ps, Counters* cnt, hipEvent_t done = nullptr);
 void fovpt_launch_build_guide(hipStream_t st, const float* cdf, int n, int segments, uint32_t* guide);
 void fovpt_launch_build_cdf(hipStream_t st, int w, int h, const float4* data, float* pdfX, float* cdfX, float* pdfY, float* cdfY, float* row_total);
 void fovpt_launch_math(hipStream_t st, int op, const float* a, const float* b, float* out, size_t n);

@@ -21,6 +21,7 @@
 // sqrt, transcendental functions from include/fovpt_detmath.h.  The only fused multiply-adds
 // are the explicit ones in the (conservative) box test.
 #include "fovpt_device.h"
+#include <hip/hip_ext.h>
 #include "../../include/fovpt_detmath.h"
 
 #ifndef FOVPT_V_STEPSTAT
@@ -1407,19 +1408,23 @@ void fovpt_launch_generate(hipStream_t st, const FrameDev& fd, PathState ps, Ray
     hipLaunchKernelGGL(k_generate, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, ps, queue0, cap, cnt, total_slots);
 }
 void fovpt_launch_traverse(hipStream_t st, SceneView sc, PathState ps, RayQueue queue, ShadowQueue sq, uint32_t cap,
-                           Counters* cnt, int it_closest, int it_shadow, int grid)
+                           Counters* cnt, int it_closest, int it_shadow, int grid, hipEvent_t done)
 {
-    hipLaunchKernelGGL(k_traverse, dim3(grid), dim3(FOVPT_BLOCK), 0, st, sc, ps, queue, sq, cap, cnt, it_closest, it_shadow);
+    // `done` rides on the kernel's own completion signal (no separate marker packet in the queue)
+    if (done) hipExtLaunchKernelGGL(k_traverse, dim3(grid), dim3(FOVPT_BLOCK), 0, st, nullptr, done, 0, sc, ps, queue, sq, cap, cnt, it_closest, it_shadow);
+    else hipLaunchKernelGGL(k_traverse, dim3(grid), dim3(FOVPT_BLOCK), 0, st, sc, ps, queue, sq, cap, cnt, it_closest, it_shadow);
 }
 void fovpt_launch_shade(hipStream_t st, const FrameDev& fd, SceneView sc, PathState ps, RayQueue queue_in, RayQueue queue_out,
-                        ShadowQueue sq, uint32_t cap, Counters* cnt, int depth, int grid)
+                        ShadowQueue sq, uint32_t cap, Counters* cnt, int depth, int grid, hipEvent_t done)
 {
-    hipLaunchKernelGGL(k_shade, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, sc, ps, queue_in, queue_out, sq, cap, cnt, depth);
+    if (done) hipExtLaunchKernelGGL(k_shade, dim3(grid), dim3(FOVPT_BLOCK), 0, st, nullptr, done, 0, fd, sc, ps, queue_in, queue_out, sq, cap, cnt, depth);
+    else hipLaunchKernelGGL(k_shade, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, sc, ps, queue_in, queue_out, sq, cap, cnt, depth);
 }
-void fovpt_launch_resolve(hipStream_t st, const FrameDev& fd, PathState ps, Counters* cnt)
+void fovpt_launch_resolve(hipStream_t st, const FrameDev& fd, PathState ps, Counters* cnt, hipEvent_t done)
 {
     dim3 grid((fd.w + 63) / 64, (fd.h + 3) / 4);
-    hipLaunchKernelGGL(k_resolve, grid, dim3(FOVPT_BLOCK), 0, st, fd, ps, cnt);
+    if (done) hipExtLaunchKernelGGL(k_resolve, grid, dim3(FOVPT_BLOCK), 0, st, nullptr, done, 0, fd, ps, cnt);
+    else hipLaunchKernelGGL(k_resolve, grid, dim3(FOVPT_BLOCK), 0, st, fd, ps, cnt);
 }
 void fovpt_launch_build_guide(hipStream_t st, const float* cdf, int n, int segments, uint32_t* guide)
 {
