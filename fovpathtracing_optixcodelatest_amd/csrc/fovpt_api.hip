@@ -35,16 +35,24 @@ struct EventPair { hipEvent_t a, b; int kind; };   // kind: 0 gen, 1 trace, 2 sh
 
 }  // namespace
 
+// Shadow-queue buffers per state set: bounce it writes buffer it % FOVPT_NSQ, so with max_depth <= FOVPT_NSQ the
+// main chain never has to wait for an occlusion launch inside a job.
+#define FOVPT_NSQ 4
+
 struct StateSet {
     DevBuf s_thr, s_rng, s_hit, s_rad, s_alpha, s_backplate, s_guide_n, s_guide_a;
-    DevBuf q_o[2], q_d[2], sq_o[2], sq_d[2], sq_vis[2], sq_occ[2], counters;     // q_*: the two radiance-ray queues (ping-pong)
+    DevBuf q_o[2], q_d[2], counters;       // q_*: the two radiance-ray queues (ping-pong)
+    DevBuf sq_o[FOVPT_NSQ], sq_d[FOVPT_NSQ], sq_vis[FOVPT_NSQ], sq_occ[FOVPT_NSQ];   // shadow queues, one per bounce in flight
     hipEvent_t ev_shade[FOVPT_MAX_ITERS + 1] = {};
     hipEvent_t ev_shadow[FOVPT_MAX_ITERS + 1] = {};
     hipEvent_t ev_done = nullptr;          // recorded after the resolve of the last job that used this set
     bool used = false;
-    DevBuf* all[27] = {&q_o[0], &q_d[0], &s_thr, &s_rng, &s_hit, &s_rad, &s_alpha, &s_backplate, &s_guide_n, &s_guide_a,
-                       &q_o[1], &q_d[1], &sq_o[0], &sq_d[0], &sq_vis[0], &sq_occ[0], &sq_o[1], &sq_d[1], &sq_vis[1], &sq_occ[1], &counters,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<DevBuf*> all()
+    {
+        std::vector<DevBuf*> v = {&q_o[0], &q_d[0], &q_o[1], &q_d[1], &s_thr, &s_rng, &s_hit, &s_rad, &s_alpha, &s_backplate, &s_guide_n, &s_guide_a, &counters};
+        for (int k = 0; k < FOVPT_NSQ; k++) { v.push_back(&sq_o[k]); v.push_back(&sq_d[k]); v.push_back(&sq_vis[k]); v.push_back(&sq_occ[k]); }
+        return v;
+    }
 };
 
 struct fovpt_ctx {
@@ -174,11 +182,12 @@ int ensure_state(fovpt_ctx* c, StateSet& S, size_t slots, size_t launches)
     HIPCHK(c, S.s_backplate.reserve(launches * v));
     if (c->cfg.write_guides) { HIPCHK(c, S.s_guide_n.reserve(slots * v)); HIPCHK(c, S.s_guide_a.reserve(slots * v)); }
     // sharded queues: FOVPT_SHARDS regions of shard_capacity(slots) entries each;
-    // the shadow queue is double-buffered because bounce it's occlusion rays may still be in flight
-    // on the shadow stream while bounce it+1 is being shaded
+    // there is one shadow queue per bounce in flight (FOVPT_NSQ): bounce it's occlusion rays may still be running
+    // on the shadow stream while later bounces are shaded
     const size_t qn = (size_t)shard_capacity(slots) * FOVPT_SHARDS;
-    for (int k = 0; k < 2; k++) {
-        HIPCHK(c, S.q_o[k].reserve(qn * v)); HIPCHK(c, S.q_d[k].reserve(qn * v));
+    for (int k = 0; k < 2; k++) { HIPCHK(c, S.q_o[k].reserve(qn * v)); HIPCHK(c, S.q_d[k].reserve(qn * v)); }
+    const int iters_max = c->cfg.max_depth + (c->any_catcher ? 25 : 0);
+    for (int k = 0; k < FOVPT_NSQ && k < iters_max; k++) {
         HIPCHK(c, S.sq_o[k].reserve(qn * v)); HIPCHK(c, S.sq_d[k].reserve(qn * v));
         HIPCHK(c, S.sq_vis[k].reserve(qn * v)); HIPCHK(c, S.sq_occ[k].reserve(qn * v));
     }
@@ -300,8 +309,8 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     ps.alpha = (float4*)S.s_alpha.p; ps.backplate = (float4*)S.s_backplate.p;
     ps.guide_n = c->cfg.write_guides ? (float4*)S.s_guide_n.p : nullptr;
     ps.guide_a = c->cfg.write_guides ? (float4*)S.s_guide_a.p : nullptr;
-    ShadowQueue sq[2];
-    for (int k = 0; k < 2; k++) {
+    ShadowQueue sq[FOVPT_NSQ];
+    for (int k = 0; k < FOVPT_NSQ; k++) {
         sq[k].o = (float4*)S.sq_o[k].p; sq[k].d = (float4*)S.sq_d[k].p;
         sq[k].val_vis = (float4*)S.sq_vis[k].p; sq[k].val_occ = (float4*)S.sq_occ[k].p;
     }
@@ -328,13 +337,14 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     // buffer of bounce it, and resolve needs everything -- it runs on the shadow stream, behind the last
     // occlusion launch (which waited for the last shade), so the main chain is free for the next job.
     { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qa, sq[0], cap, cnt, 0, -1, grid); }
+    const int nsq = iters < FOVPT_NSQ ? iters : FOVPT_NSQ;        // (only that many buffers are allocated)
     for (int it = 0; it < iters; it++) {
-        if (it >= 2) HIPCHK(c, hipStreamWaitEvent(st, S.ev_shadow[it - 2], 0));
+        if (it >= nsq) HIPCHK(c, hipStreamWaitEvent(st, S.ev_shadow[it - nsq], 0));
         // the events ride on the kernels' own completion signals (hipExtLaunchKernel): a separate
         // hipEventRecord would put a marker packet between shade(it) and closest(it+1), ~6 us on the critical path
-        { Timed t(c, 2); fovpt_launch_shade(st, fd, sc, ps, qa, qb, sq[it & 1], cap, cnt, it, grid, S.ev_shade[it]); }
+        { Timed t(c, 2); fovpt_launch_shade(st, fd, sc, ps, qa, qb, sq[it % nsq], cap, cnt, it, grid, S.ev_shade[it]); }
         HIPCHK(c, hipStreamWaitEvent(ss, S.ev_shade[it], 0));
-        { Timed t(c, 3, ss); fovpt_launch_traverse(ss, sc, ps, qb, sq[it & 1], cap, cnt, -1, it, c->grid_shadow, S.ev_shadow[it]); }
+        { Timed t(c, 3, ss); fovpt_launch_traverse(ss, sc, ps, qb, sq[it % nsq], cap, cnt, -1, it, c->grid_shadow, S.ev_shadow[it]); }
         if (it + 1 < iters) { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qb, sq[0], cap, cnt, it + 1, -1, grid); }
         const RayQueue tmp = qa; qa = qb; qb = tmp;
     }
@@ -415,7 +425,7 @@ void fovpt_destroy(fovpt_ctx* c)
             if (S.ev_shadow[k]) (void)hipEventDestroy(S.ev_shadow[k]);
         }
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
-        for (DevBuf* b : S.all) if (b) b->release();
+        for (DevBuf* b : S.all()) b->release();
     }
     free_scene(c);
     DevBuf* bufs[] = {&c->tri_tc, &c->meshes, &c->textures, &c->pr_data, &c->pr_pdfx, &c->pr_cdfx, &c->pr_pdfy, &c->pr_cdfy,
@@ -866,7 +876,7 @@ int fovpt_debug_buffer(fovpt_ctx* c, const char* name, void** ptr, size_t* bytes
     if (!c || !name || !ptr || !bytes) return FOVPT_E_INVALID;
     StateSet& S = c->set[(c->jobs + 1u) & 1u];            // the set the most recent job used
     struct { const char* n; DevBuf* b; } tab[] = {
-        {"sq_o", &S.sq_o[1]}, {"sq_d", &S.sq_d[1]}, {"sq_vis", &S.sq_vis[1]}, {"sq_occ", &S.sq_occ[1]}, {"counters", &S.counters},
+        {"sq_o", &S.sq_o[0]}, {"sq_d", &S.sq_d[0]}, {"sq_vis", &S.sq_vis[0]}, {"sq_occ", &S.sq_occ[0]}, {"counters", &S.counters},
         {"hit", &S.s_hit}, {"queue_a_o", &S.q_o[0]}, {"queue_a_d", &S.q_d[0]}, {"queue_b_o", &S.q_o[1]}, {"queue_b_d", &S.q_d[1]},
     };
     for (auto& t : tab)
