@@ -1160,7 +1160,11 @@ __device__ inline uint32_t make_color(const V3& c)                              
 }
 
 // candidate launch-index range along one axis for pixel coordinate x (resolve)
-__device__ inline void writer_range(uint32_t x, uint32_t frame_dim, uint32_t factor, int fill, uint32_t off, uint32_t grid, long long& lo, long long& hi)
+// `wrap` (>= 0 only on the clamped edge): launch indices 0 .. wrap have a "negative" pixel index, which in the
+// reference's unsigned arithmetic is a huge one and is clamped onto this edge too (deviceProgram.cu:433, :554).
+// They only ever pass the ring test when the gaze point itself is such a wrapped coordinate.
+__device__ inline void writer_range(uint32_t x, uint32_t frame_dim, uint32_t factor, int fill, uint32_t off, uint32_t grid, long long& lo, long long& hi,
+                                    long long& wrap)
 {
     // r = x - (int32)off, a = max(0, ceil((r - (fill-1)) / f)), b = floor(r / f) (or grid-1 on the clamped edge).
     // Integer division is a long software routine on the GPU: power-of-two factors (1, 2, 4 in every
@@ -1183,6 +1187,14 @@ __device__ inline void writer_range(uint32_t x, uint32_t frame_dim, uint32_t fac
         if (b > (long long)grid - 1) b = (long long)grid - 1;
     }
     lo = a; hi = b;
+    wrap = -1;
+    if (x + 1 == frame_dim && (int32_t)off < 0) {
+        const long long neg = -(long long)(int32_t)off;                       // index of launch l is l*f - neg
+        long long cnt = (neg + (long long)f - 1) / (long long)f;              // l*f < neg
+        if (cnt > (long long)grid) cnt = grid;
+        wrap = cnt - 1;
+        if (wrap >= lo) wrap = lo - 1;                                        // (already part of [lo, hi])
+    }
 }
 
 // Resolve as a tiled LDS reduction.  A block owns a 64 x 4 pixel tile.
@@ -1225,13 +1237,18 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_resolve(const FrameDev fd, Path
             if (p >= fd.npass || state != 0) continue;
             const PassDev& P = fd.pass[p];
             if (P.fill <= 0) continue;
-            long long xa, xb, ya, yb;
-            writer_range(x, (uint32_t)fd.w, P.fx, P.fill, P.offx, P.gw, xa, xb);
-            writer_range(y, (uint32_t)fd.h, P.fy, P.fill, P.offy, P.gh, ya, yb);
+            long long xa, xb, ya, yb, xw, yw;
+            writer_range(x, (uint32_t)fd.w, P.fx, P.fill, P.offx, P.gw, xa, xb, xw);
+            writer_range(y, (uint32_t)fd.h, P.fy, P.fill, P.offy, P.gh, ya, yb, yw);
             if (ya < (long long)P.row0) ya = P.row0;           // only this chunk's launch rows
             if (yb > (long long)P.row1 - 1) yb = (long long)P.row1 - 1;
-            for (long long ly = yb; ly >= ya && state == 0; ly--) {
-                for (long long lx = xb; lx >= xa; lx--) {
+            if (yw > (long long)P.row1 - 1) yw = (long long)P.row1 - 1;
+            const long long y_end = yw >= (long long)P.row0 ? (long long)P.row0 : ya, x_end = xw >= 0 ? 0 : xa;
+            // candidates in descending launch order: [ya, yb] then the wrapped rows [row0, yw]; same along x
+            for (long long ly = yb; ly >= y_end && state == 0; ly--) {
+                if (ly < ya && ly > yw) { ly = yw + 1; continue; }
+                for (long long lx = xb; lx >= x_end; lx--) {
+                    if (lx < xa && lx > xw) { lx = xw + 1; continue; }
                     uint32_t ix, iy;
                     if (!ring_alive(fd, P, (uint32_t)lx, (uint32_t)ly, ix, iy)) continue;
                     state = launch_owned(fd, p, (uint32_t)lx, (uint32_t)ly) ? 1 : 2;

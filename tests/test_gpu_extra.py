@@ -385,3 +385,32 @@ def test_small_geometry_seen_from_far_away(oracle):
         covered = int((F.accum[..., :3].sum(-1) > 1.0).sum())
         assert covered > 0.15 * size[0] * size[1]
         r.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_configurations(oracle, seed):
+    """Seeded random frame sizes (odd ones too), radii (zero, equal, larger than the frame), sample counts,
+    depths, gaze points (also off the frame), subframe indices, uniform / foveated / accumulate, materials and
+    probes: whatever the reference's code does with them, both sides must do the same."""
+    rng = np.random.default_rng(1000 + seed)
+    w, h = int(rng.integers(17, 150)), int(rng.integers(9, 100))
+    model = scenes.cornell_box() if seed % 3 == 0 else scenes.atrium(int(rng.integers(300, 6000)), seed=int(rng.integers(1, 99)),
+                                                                        material=("app", "diffuse", "matte")[seed % 3])
+    cam = scenes.CORNELL_CAMERA if seed % 3 == 0 else scenes.ATRIUM_CAMERA
+    probe = (scenes.sky_probe(), scenes.ambient_probe(w, h, 2.5), scenes.ambient_probe(16, 8, 0.7))[int(rng.integers(0, 3))]
+    if rng.random() < 0.3:
+        cfg = cfg_uniform(int(rng.integers(1, 6)), max_depth=int(rng.integers(1, 7)))
+    else:
+        r_i = int(rng.integers(0, 60))
+        r_o = r_i + int(rng.integers(0, 120))                # (fovpt_set_config refuses r_outer < r_inner)
+        cfg = cfg_foveated(r_i, r_o, tuple(int(x) for x in rng.integers(1, 7, 3)), max_depth=int(rng.integers(1, 7)))
+    cfg.accumulate = int(rng.random() < 0.3)
+    gaze = (int(rng.integers(-20, w + 20)), int(rng.integers(-20, h + 20)))
+    sub = int(rng.integers(0, 4))
+    r = make_gpu(model, probe, cam, (w, h), cfg, gaze=gaze, subframe_index=sub)
+    S, F = make_oracle(oracle, model, probe, cam, (w, h), gaze=gaze, subframe_index=sub)
+    for _ in range(2):                                   # two frames: subframe_index advances, accumulate blends
+        r.render()
+        oracle.render(S, F, cfg)
+        assert _bits_equal(r.downloadAccum(), F.accum) and np.array_equal(r.downloadPixels(), F.frame), (w, h, gaze, sub)
+    r.close()
