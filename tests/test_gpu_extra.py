@@ -387,7 +387,10 @@ def test_small_geometry_seen_from_far_away(oracle):
         r.close()
 
 
-@pytest.mark.parametrize("seed", range(10))
+_FUZZ = range(int(os.environ.get("FOVPT_FUZZ_FROM", "0")), int(os.environ.get("FOVPT_FUZZ_TO", "10")))      # widen for a sweep
+
+
+@pytest.mark.parametrize("seed", _FUZZ)
 def test_random_configurations(oracle, seed):
     """Seeded random frame sizes (odd ones too), radii (zero, equal, larger than the frame), sample counts,
     depths, gaze points (also off the frame), subframe indices, uniform / foveated / accumulate, materials and
