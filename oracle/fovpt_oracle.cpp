@@ -747,6 +747,7 @@ struct Ctx {
     ProbeH probe;
     Opts opt;
     Counters* cnt;
+    const fovpt_float4* accum_before = nullptr;     // accum_buffer as it was when the launch began (see launch())
 };
 
 // deviceProgram.cu:303-344 (SampleLights) and :347-387 (SampleShadow, want_occluded = true)
@@ -954,7 +955,7 @@ void raygen(const Ctx& C, uint32_t lx, uint32_t ly)
                 // PT_sv4_vmv2/deviceProgram.cu:545-553 (commented out in PT_sv5_/deviceProgram.cu:565-581)
                 accum_color = clamp3(accum_color, 0.0f, 10.0f);
                 const float alpha_value = 1.0f / static_cast<float>(subframe_index + 1);
-                const fovpt_float4 pv = params.frame.accum_buffer[image_index];
+                const fovpt_float4 pv = C.accum_before ? C.accum_before[image_index] : params.frame.accum_buffer[image_index];
                 const f3 accum_color_prev = mk3(pv.x, pv.y, pv.z);
                 accum_color = lerp3(accum_color_prev, accum_color, alpha_value);
             }
@@ -992,6 +993,15 @@ void launch(const Scene& S, const fovpt_launch_params& lp, uint32_t width, uint3
     }
     int nt = std::max(1, opt.nthreads);
     if (clamps) nt = 1;
+    // Accumulate mode (PT_sv4_vmv2 :545-553) reads accum_buffer[pixel] and writes it back.  When several launch
+    // indices of ONE launch write the same pixel (clamped or overlapping fills) that is a data race in the
+    // reference.  It is resolved here the way a GPU resolves it when the reads precede the conflicting writes:
+    // every writer blends with the value from BEFORE the launch, and the last one in launch order stays.
+    std::vector<fovpt_float4> before;
+    if (clamps && opt.accumulate && lp.frame.subframe_index > 0 && !lp.frame.redraw) {
+        before.assign(lp.frame.accum_buffer, lp.frame.accum_buffer + (size_t)lp.frame.size.x * lp.frame.size.y);
+        C.accum_before = before.data();
+    }
     if (nt == 1) {
         for (uint32_t y = 0; y < height; y++)
             for (uint32_t x = 0; x < width; x++) raygen(C, x, y);

@@ -417,3 +417,44 @@ def test_random_configurations(oracle, seed):
         oracle.render(S, F, cfg)
         assert _bits_equal(r.downloadAccum(), F.accum) and np.array_equal(r.downloadPixels(), F.frame), (w, h, gaze, sub)
     r.close()
+
+
+_FUZZ_L = range(int(os.environ.get("FOVPT_FUZZL_FROM", "0")), int(os.environ.get("FOVPT_FUZZL_TO", "12")))
+
+
+@pytest.mark.parametrize("seed", _FUZZ_L)
+def test_random_single_launches(oracle, seed):
+    """fovpt_launch = one optixLaunch with caller-chosen parameters: random factor (also 3), fill (0 .. larger than
+    the factor), offsets that wrap below zero or push the grid off the frame, rings, gaze points on and off the
+    frame, grids smaller and larger than the frame, two launches into the same frame."""
+    rng = np.random.default_rng(5000 + seed)
+    w, h = int(rng.integers(12, 90)), int(rng.integers(8, 70))
+    model = scenes.cornell_box()
+    probe = scenes.sky_probe()
+    cfg = abi.Config.reference_default()
+    cfg.max_depth, cfg.accumulate = int(rng.integers(1, 4)), int(rng.random() < 0.3)
+    r = make_gpu(model, probe, scenes.CORNELL_CAMERA, (w, h), cfg)
+    S, F = make_oracle(oracle, model, probe, scenes.CORNELL_CAMERA, (w, h))
+    for launch_no in range(2):
+        fx, fy = (int(v) for v in rng.integers(1, 5, 2))
+        fill = int(rng.integers(0, 6))
+        gaze = (int(rng.integers(-8, w + 8)) & 0xFFFFFFFF, int(rng.integers(-8, h + 8)) & 0xFFFFFFFF)
+        off = (int(rng.integers(-30, w)) & 0xFFFFFFFF, int(rng.integers(-30, h)) & 0xFFFFFFFF)
+        r_i = float(rng.integers(0, 20))
+        r_o = 1e9 if rng.random() < 0.4 else r_i + float(rng.integers(0, 60))
+        gw, gh = int(rng.integers(1, w // fx + 12)), int(rng.integers(1, h // fy + 12))
+        spp, sub, redraw = int(rng.integers(1, 4)), int(rng.integers(0, 3)), int(rng.integers(0, 2))
+        for lp in (r.launchParams, F.lp):
+            f = lp.frame
+            f.factor.x, f.factor.y, f.factor.z, f.fillSize = fx, fy, 1, fill
+            f.r_inner, f.r_outer = r_i, r_o
+            f.c.x, f.c.y = gaze
+            f.offset.x, f.offset.y = off
+            f.redraw, f.subframe_index = redraw, sub
+            lp.samples_per_launch = spp
+        r.launch(gw, gh)
+        r.synchronize()
+        oracle.launch(S, F, gw, gh, max_depth=cfg.max_depth, accumulate=cfg.accumulate)
+        assert _bits_equal(r.downloadAccum(), F.accum) and np.array_equal(r.downloadPixels(), F.frame), \
+            (seed, launch_no, (w, h), (fx, fy), fill, gaze, off, (r_i, r_o), (gw, gh), spp, sub, redraw)
+    r.close()
