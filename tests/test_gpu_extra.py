@@ -458,3 +458,52 @@ def test_random_single_launches(oracle, seed):
         assert _bits_equal(r.downloadAccum(), F.accum) and np.array_equal(r.downloadPixels(), F.frame), \
             (seed, launch_no, (w, h), (fx, fy), fill, gaze, off, (r_i, r_o), (gw, gh), spp, sub, redraw)
     r.close()
+
+
+_FUZZ_M = range(int(os.environ.get("FOVPT_FUZZM_FROM", "0")), int(os.environ.get("FOVPT_FUZZM_TO", "8")))
+
+
+@pytest.mark.parametrize("seed", _FUZZ_M)
+def test_random_shards_chunks_and_guides(oracle, monkeypatch, seed):
+    """Random frame configurations run (a) as world = 2..8 tile shards with random tile sizes, (b) cut into chunks
+    by a small job budget, (c) with the denoiser guide buffers on: shards add up to the oracle's frame, chunked
+    and unchunked frames are the oracle's frame, guides are the oracle's guides."""
+    rng = np.random.default_rng(9000 + seed)
+    w, h = int(rng.integers(40, 160)), int(rng.integers(24, 100))
+    model = scenes.atrium(int(rng.integers(500, 6000)), seed=int(rng.integers(1, 99)))
+    probe = scenes.sky_probe() if seed % 2 else scenes.ambient_probe(w, h, 2.5)
+    if rng.random() < 0.25:
+        cfg = cfg_uniform(int(rng.integers(1, 4)), max_depth=int(rng.integers(1, 5)))
+    else:
+        r_i = int(rng.integers(2, 30))
+        cfg = cfg_foveated(r_i, r_i + int(rng.integers(1, 60)), tuple(int(x) for x in rng.integers(1, 6, 3)), max_depth=int(rng.integers(1, 5)))
+    gaze = (int(rng.integers(0, w)), int(rng.integers(0, h)))
+    S, F = make_oracle(oracle, model, probe, scenes.ATRIUM_CAMERA, (w, h), gaze=gaze)
+    gcfg = cfg.copy(); gcfg.write_guides = 1
+    oracle.render(S, F, gcfg)
+    # (c) guides + the plain frame
+    r = make_gpu(model, probe, scenes.ATRIUM_CAMERA, (w, h), gcfg, gaze=gaze)
+    r.render()
+    f = r.launchParams.frame
+    for ptr, want in ((f.normal_buffer, F.normal), (f.color_buffer, F.color), (f.albedo_buffer, F.albedo)):
+        assert _bits_equal(r.download(ptr, np.empty((h, w, 4), np.float32)), want)
+    assert _bits_equal(r.downloadAccum(), F.accum) and np.array_equal(r.downloadPixels(), F.frame)
+    r.close()
+    # (a) shards
+    world = int(rng.integers(2, 9))
+    tile = (int(rng.integers(1, 17)), int(rng.integers(1, 9)))
+    total_f = np.zeros((h, w), np.uint64); total_a = np.zeros((h, w, 4), np.float32)
+    for rank in range(world):
+        c = cfg.copy()
+        c.rank, c.world, c.tile_w, c.tile_h = rank, world, tile[0], tile[1]
+        rr = make_gpu(model, probe, scenes.ATRIUM_CAMERA, (w, h), c, gaze=gaze)
+        rr.render()
+        total_f += rr.downloadPixels(); total_a += rr.downloadAccum()
+        rr.close()
+    assert np.array_equal(total_f.astype(np.uint32), F.frame) and _bits_equal(total_a, F.accum), (world, tile)
+    # (b) chunks
+    monkeypatch.setenv("FOVPT_SLOT_BUDGET", str(int(rng.integers(600, 5000))))
+    rc = make_gpu(model, probe, scenes.ATRIUM_CAMERA, (w, h), cfg, gaze=gaze)
+    rc.render()
+    assert _bits_equal(rc.downloadAccum(), F.accum) and np.array_equal(rc.downloadPixels(), F.frame)
+    rc.close()
