@@ -507,3 +507,56 @@ def test_random_shards_chunks_and_guides(oracle, monkeypatch, seed):
     rc.render()
     assert _bits_equal(rc.downloadAccum(), F.accum) and np.array_equal(rc.downloadPixels(), F.frame)
     rc.close()
+
+
+_FUZZ_S = range(int(os.environ.get("FOVPT_FUZZS_FROM", "0")), int(os.environ.get("FOVPT_FUZZS_TO", "10")))
+
+
+@pytest.mark.parametrize("seed", _FUZZ_S)
+def test_random_scenes_and_materials(oracle, seed):
+    """Random triangle soups with duplicated and coplanar-overlapping triangles (closest-hit ties: lowest primitive
+    id), zero-area triangles, several meshes with random Disney parameters over their whole ranges (transmission 0
+    and 1, eta 0, subsurface, clearcoat, roughness 0 ...), emitters, textured meshes, sometimes a shadow catcher."""
+    rng = np.random.default_rng(7000 + seed)
+    meshes = []
+    textures = []
+    nmesh = int(rng.integers(1, 6))
+    for m in range(nmesh):
+        n = int(rng.integers(1, 200))
+        centre = rng.uniform(-4, 4, (n, 1, 3)) * np.float32([1.0, 0.4, 1.0])
+        tri = centre + rng.uniform(-1.2, 1.2, (n, 3, 3))
+        if n > 4:
+            tri[1] = tri[0]                                       # exact duplicate: the lower primitive id wins
+            tri[2] = tri[0] + np.float32([0.3, 0.0, 0.1]) * 0.0 + (tri[0][1] - tri[0][0]) * 0.25   # coplanar, shifted along an edge
+            tri[3][2] = tri[3][1]                                 # zero area
+        v = tri.reshape(-1, 3).astype(np.float32)
+        idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+        mat = abi.Material.reference_default()
+        mat.color.set(rng.uniform(0, 1, 3)); mat.emission.set(rng.uniform(0, 3, 3) if rng.random() < 0.3 else (0, 0, 0))
+        pick = lambda *vals: float(vals[int(rng.integers(0, len(vals)))])
+        mat.transmission = pick(0.0, 1.0, rng.uniform(0, 1)); mat.metallic = pick(0.0, 1.0, rng.uniform(0, 1))
+        mat.roughness = pick(0.0, 1.0, rng.uniform(0, 1)); mat.subsurface = pick(0.0, 0.0, rng.uniform(0, 1))
+        mat.specular = pick(0.0, 1.0, rng.uniform(0, 1)); mat.specularTint = pick(0.0, 1.0, rng.uniform(0, 1))
+        mat.clearcoat = pick(0.0, 1.0, rng.uniform(0, 1)); mat.clearcoatGloss = pick(0.0, 1.0, rng.uniform(0, 1))
+        mat.eta = pick(0.0, 1.0, 1.5, rng.uniform(1, 2))
+        if m == 0 and rng.random() < 0.3:
+            mat.flags = abi.MATERIAL_FLAG_SHADOW_CATCHER
+        tc, tid = None, -1
+        if rng.random() < 0.5:
+            tw, th = int(rng.integers(1, 9)), int(rng.integers(1, 9))           # any size, not only powers of two
+            textures.append(rng.integers(0, 2 ** 32, (th, tw), dtype=np.uint64).astype(np.uint32))
+            tid = len(textures) - 1
+            tc = rng.uniform(-2, 3, (3 * n, 2)).astype(np.float32)             # wraps in both directions
+        meshes.append(scenes.TriangleMesh(vertex=v, index=idx, material=mat, texcoord=tc, texture_id=tid))
+    model = scenes.Model(meshes=meshes, textures=textures)
+    cam = dict(eye=(0.0, 2.5, 11.0), lookat=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fovy=50.0)
+    size = (int(rng.integers(40, 120)), int(rng.integers(30, 90)))
+    cfg = cfg_uniform(int(rng.integers(1, 4)), max_depth=int(rng.integers(1, 6)))
+    probe = scenes.sky_probe() if seed % 2 else scenes.ambient_probe(32, 16, 1.0)
+    r = make_gpu(model, probe, cam, size, cfg)
+    r.render()
+    S, F = make_oracle(oracle, model, probe, cam, size)
+    cnt = oracle.render(S, F, cfg)
+    assert _bits_equal(r.downloadAccum(), F.accum) and np.array_equal(r.downloadPixels(), F.frame)
+    assert r.stats().paths == cnt[2]
+    r.close()
