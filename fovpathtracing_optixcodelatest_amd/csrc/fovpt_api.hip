@@ -484,9 +484,10 @@ int fovpt_set_scene(fovpt_ctx* c, const fovpt_mesh_desc* meshes, int num_meshes,
             mesh_of[t] = (uint32_t)m;
         }
     }
-    float* d_flat = nullptr; uint32_t* d_mesh_of = nullptr;
-    HIPCHK(c, hipMalloc(&d_flat, flat.size() * 4));
-    HIPCHK(c, hipMalloc(&d_mesh_of, mesh_of.size() * 4));
+    struct Tmp { void* p = nullptr; ~Tmp() { if (p) (void)hipFree(p); } } t_flat, t_mesh_of;      // freed on every return path
+    HIPCHK(c, hipMalloc(&t_flat.p, flat.size() * 4));
+    HIPCHK(c, hipMalloc(&t_mesh_of.p, mesh_of.size() * 4));
+    float* d_flat = (float*)t_flat.p; uint32_t* d_mesh_of = (uint32_t*)t_mesh_of.p;
     HIPCHK(c, hipMemcpy(d_flat, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(d_mesh_of, mesh_of.data(), mesh_of.size() * 4, hipMemcpyHostToDevice));
     if (any_tc) {
@@ -528,7 +529,6 @@ int fovpt_set_scene(fovpt_ctx* c, const fovpt_mesh_desc* meshes, int num_meshes,
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    (void)hipFree(d_flat); (void)hipFree(d_mesh_of);
     if (be != hipSuccess) return fail(c, FOVPT_E_DEVICE, "LBVH build: %s", errbuf);
     if (3 * br.max_depth + 1 > FOVPT_STACK) {       // a wide node leaves at most 3 entries behind
         (void)hipFree(br.nodes); (void)hipFree(br.tris);
