@@ -324,6 +324,9 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     qb.o = (float4*)S.q_o[1].p; qb.d = (float4*)S.q_d[1].p;
 
     // (the queue counters are zero: at allocation, and again by the resolve of the set's previous job)
+#if FOVPT_V_STEPSTAT
+    HIPCHK(c, hipMemsetAsync(cnt, 0, offsetof(Counters, stat_radiance), st));      // the diagnostic build keeps them after the job
+#endif
     const int grid = c->grid;
     const uint32_t cap = shard_capacity((size_t)slots);
     { Timed t(c, 0); fovpt_launch_generate(st, fd, ps, qa, cap, cnt, (uint32_t)slots, grid); }

@@ -9,6 +9,9 @@
 
 #define FOVPT_WAVE 64
 #define FOVPT_BLOCK 256
+#ifndef FOVPT_V_STEPSTAT
+#define FOVPT_V_STEPSTAT 0         // 1: diagnostic build (tools/stepstat.py, tools/raystat.py)
+#endif
 #ifndef FOVPT_LEAF_MAX
 #define FOVPT_LEAF_MAX 4          // triangles per BVH leaf (<= 8: three bits in the leaf code)
 #endif

@@ -24,9 +24,6 @@
 #include <hip/hip_ext.h>
 #include "../../include/fovpt_detmath.h"
 
-#ifndef FOVPT_V_STEPSTAT
-#define FOVPT_V_STEPSTAT 0
-#endif
 // waves per SIMD the traversal kernel is compiled for (caps VGPRs at 64); measured best
 #ifndef FOVPT_V_WAVES
 #define FOVPT_V_WAVES 8
@@ -1208,7 +1205,7 @@ __device__ inline void writer_range(uint32_t x, uint32_t frame_dim, uint32_t fac
 //      is the last kernel of a job and nothing in it reads them
 __global__ __launch_bounds__(FOVPT_BLOCK) void k_resolve(const FrameDev fd, PathState ps, Counters* __restrict__ cnt)
 {
-    if (blockIdx.x == 0 && blockIdx.y == 0) {
+    if (!FOVPT_V_STEPSTAT && blockIdx.x == 0 && blockIdx.y == 0) {     // (a diagnostic build keeps them for tools/raystat.py)
         uint32_t* w = &cnt->shard[0][0];
         for (uint32_t i = threadIdx.x; i < FOVPT_SHARDS * FOVPT_SHARD_STRIDE; i += FOVPT_BLOCK) w[i] = 0u;
     }
