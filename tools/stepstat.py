@@ -13,6 +13,7 @@ r.setCamera(renderer.Camera(cam["eye"], cam["lookat"], cam["up"], cam["fovy"], W
 r.setProbe(renderer.ProbeData(scenes.ambient_probe(W, H, 2.5)).BuildCDF())
 cfg = abi.Config.reference_default(); cfg.r_inner, cfg.r_outer = 148, 482
 cfg.spp_periphery, cfg.spp_middle, cfg.spp_fovea = 1, 2, 8
+cfg.max_depth = int(os.environ.get("FOVPT_DEPTH", "4"))
 r.config = cfg
 r.launchParams.frame.c.x, r.launchParams.frame.c.y = W // 2, H // 2
 r.reset_stats()
