@@ -77,6 +77,8 @@ struct fovpt_ctx {
     bool rows_identical = false;           // every row of data / pdfX / cdfX equals row 0 bit for bit
     // frame buffers (resize)
     DevBuf fb_frame, fb_accum, fb_color, fb_normal, fb_albedo;
+    DevBuf accum_before;                   // accumulate mode, chunked launch: the accum buffer as it was before the launch
+    bool use_accum_before = false;
     // Wavefront state, TWO sets used alternately by consecutive jobs: the tail of job k (its last occlusion
     // rays and its resolve, on the shadow stream) runs beside the head of job k+1 (generate, camera rays)
     StateSet set[2];
@@ -231,6 +233,17 @@ int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passe
         }
         for (int p = 0; p < npass; p++) {
             const PassDev& P = passes_in[p];
+            // Accumulate mode blends with the pixel's value from BEFORE the launch (a pass of render() = one
+            // optixLaunch).  The chunks of a pass are separate jobs, so a pixel that two of them write (clamped
+            // or overlapping fills) would otherwise be blended twice: keep a copy for the chunks to read.
+            if (c->cfg.accumulate && P.subframe > 0 && !P.redraw) {
+                const size_t nb = (size_t)lp->frame.size.x * lp->frame.size.y * 16;
+                HIPCHK(c, c->accum_before.reserve(nb));
+                HIPCHK(c, hipMemcpyAsync(c->accum_before.p, lp->frame.accum_buffer, nb, hipMemcpyDeviceToDevice, c->shadow_stream));
+                c->use_accum_before = true;
+            } else {
+                c->use_accum_before = false;
+            }
             const uint64_t per_row = (uint64_t)P.gw * P.spp;
             if (per_row == 0 || P.gh == 0) continue;
             if (per_row > budget) return fail(c, FOVPT_E_INVALID, "one launch row needs %llu sample slots (budget %llu)", (unsigned long long)per_row, (unsigned long long)budget);
@@ -281,6 +294,7 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     fd.probe_row_mul = (c->rows_identical && lp->probe.data == (fovpt_float4*)c->pr_data.p && lp->probe.pdfValuesX == (float*)c->pr_pdfx.p
                         && lp->probe.cdfValuesX == (float*)c->pr_cdfx.p && lp->probe.width == c->guide_w && lp->probe.height == c->guide_h) ? 0 : 1;
     fd.accum = lp->frame.accum_buffer;
+    fd.accum_prev = (chunked && c->use_accum_before) ? (const fovpt_float4*)c->accum_before.p : lp->frame.accum_buffer;
     fd.frame = lp->frame.frame_buffer;
     if (c->cfg.write_guides) {
         if (c->any_catcher) return fail(c, FOVPT_E_INVALID, "write_guides is not available with shadow-catcher materials");
@@ -432,7 +446,7 @@ void fovpt_destroy(fovpt_ctx* c)
     }
     free_scene(c);
     DevBuf* bufs[] = {&c->tri_tc, &c->meshes, &c->textures, &c->pr_data, &c->pr_pdfx, &c->pr_cdfx, &c->pr_pdfy, &c->pr_cdfy,
-                      &c->fb_frame, &c->fb_accum, &c->fb_color, &c->fb_normal, &c->fb_albedo};
+                      &c->fb_frame, &c->fb_accum, &c->fb_color, &c->fb_normal, &c->fb_albedo, &c->accum_before};
     for (DevBuf* b : bufs) b->release();
     (void)hipStreamDestroy(c->stream);
     (void)hipStreamDestroy(c->shadow_stream);

@@ -98,6 +98,7 @@ struct FrameDev {
     const uint32_t* guide_y;
     int32_t probe_row_mul;        // 0 when all probe rows are identical (constant ambient probe), else 1
     fovpt_float4* accum;
+    const fovpt_float4* accum_prev;   // what accumulate mode blends with: accum itself, or its copy from before a chunked launch
     uint32_t* frame;
     fovpt_float4 *g_normal, *g_color, *g_albedo;   // denoiser guide targets (null unless write_guides)
     uint32_t total_slots;

@@ -1322,7 +1322,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_resolve(const FrameDev fd, Path
             // PT_sv4_vmv2/deviceProgram.cu:545-553: clamp + running mean against THIS pixel's history
             V3 accum_color = clamp3(v3(a), 0.0f, 10.0f);
             const float alpha_value = 1.0f / (float)(P.subframe + 1);
-            const fovpt_float4 pv = fd.accum[image_index];
+            const fovpt_float4 pv = fd.accum_prev[image_index];
             accum_color = lerp3(v3(pv.x, pv.y, pv.z), accum_color, alpha_value);
             a = f4(accum_color, 1.0f);
             rgba = make_color(reinhard(accum_color * 16.0f, 1.0f));

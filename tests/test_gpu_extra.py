@@ -423,11 +423,14 @@ _FUZZ_L = range(int(os.environ.get("FOVPT_FUZZL_FROM", "0")), int(os.environ.get
 
 
 @pytest.mark.parametrize("seed", _FUZZ_L)
-def test_random_single_launches(oracle, seed):
+def test_random_single_launches(oracle, monkeypatch, seed):
     """fovpt_launch = one optixLaunch with caller-chosen parameters: random factor (also 3), fill (0 .. larger than
     the factor), offsets that wrap below zero or push the grid off the frame, rings, gaze points on and off the
-    frame, grids smaller and larger than the frame, two launches into the same frame."""
+    frame, grids smaller and larger than the frame, two launches into the same frame; every other seed with a
+    job budget so small that the launch is cut into chunks of rows."""
     rng = np.random.default_rng(5000 + seed)
+    if seed % 2:
+        monkeypatch.setenv("FOVPT_SLOT_BUDGET", str(int(np.random.default_rng(seed).integers(400, 2500))))     # >= one launch row
     w, h = int(rng.integers(12, 90)), int(rng.integers(8, 70))
     model = scenes.cornell_box()
     probe = scenes.sky_probe()
