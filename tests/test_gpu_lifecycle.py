@@ -1,6 +1,8 @@
 """Lifecycle / API-usage parity: what PT_sv5_/main.cpp does around render() -- repeated frames,
 moving gaze and camera, subframe bookkeeping, resize, scene and probe replacement, depth and spp
 settings -- each frame checked bit-exactly against the oracle driven the same way."""
+import os
+
 import numpy as np
 import pytest
 
@@ -242,4 +244,71 @@ def test_stereo_asymmetric_frusta(oracle):
     wlen = np.linalg.norm(fwd)
     b = np.array(r.launchParams.camera.U.tolist() + r.launchParams.camera.V.tolist()) / wlen
     assert np.allclose(a, b, rtol=1e-4, atol=1e-5)
+    r.close()
+
+
+_FUZZ_LC = range(int(os.environ.get("FOVPT_FUZZLC_FROM", "0")), int(os.environ.get("FOVPT_FUZZLC_TO", "6")))
+
+
+@pytest.mark.parametrize("seed", _FUZZ_LC)
+def test_random_lifecycle(oracle, seed):
+    """One renderer through a random sequence of what an application does between frames: resize, new probe,
+    new camera, new gaze point, other radii / sample counts / depth / mode, subframe index set or left running,
+    asynchronous frames back to back (the two state sets alternate) -- after every frame the image is the oracle's."""
+    rng = np.random.default_rng(12000 + seed)
+    model = scenes.cornell_box() if seed % 2 else scenes.atrium(int(rng.integers(500, 4000)), seed=3 + seed)
+    base_cam = scenes.CORNELL_CAMERA if seed % 2 else scenes.ATRIUM_CAMERA
+    S = oracle.OracleScene(model)
+    size = (int(rng.integers(30, 120)), int(rng.integers(20, 90)))
+    probe_data = scenes.sky_probe()
+    cfg = cfg_foveated(8, 24, (1, 2, 4), max_depth=3)
+    cam = dict(base_cam)
+    r = make_gpu(model, probe_data, cam, size, cfg)
+    F = oracle.OracleFrame(size[0], size[1], oracle.HostProbe(probe_data), cam)
+
+    def set_camera():
+        r.setCamera(renderer.Camera(cam["eye"], cam["lookat"], cam["up"], cam["fovy"], size[0] / float(size[1])))
+        U, V, W = oracle.camera_uvw(cam["eye"], cam["lookat"], cam["up"], cam["fovy"], size[0] / float(size[1]))
+        F.lp.camera.eye.set(cam["eye"]); F.lp.camera.U.set(U); F.lp.camera.V.set(V); F.lp.camera.W.set(W)
+
+    for step in range(10):
+        op = int(rng.integers(0, 7))
+        if op == 0:                                                   # window resized: buffers start from zero
+            size = (int(rng.integers(30, 120)), int(rng.integers(20, 90)))
+            sub, gaze = int(F.lp.frame.subframe_index), (int(F.lp.frame.c.x), int(F.lp.frame.c.y))
+            r.resize(size)
+            F = oracle.OracleFrame(size[0], size[1], oracle.HostProbe(probe_data), cam, gaze=gaze, subframe_index=sub)
+            r.launchParams.frame.subframe_index = sub
+            set_camera()
+        elif op == 1:                                                 # other environment
+            probe_data = (scenes.sky_probe(), scenes.ambient_probe(size[0], size[1], 2.5), scenes.ambient_probe(24, 12, 0.8))[int(rng.integers(0, 3))]
+            r.setProbe(renderer.ProbeData(probe_data).BuildCDF())
+            hp = oracle.HostProbe(probe_data)
+            F.probe = hp; F.lp.probe = hp.struct
+        elif op == 2:                                                 # camera moved
+            e = np.asarray(base_cam["eye"], np.float64)
+            cam = dict(base_cam, eye=tuple(float(x) for x in e + rng.uniform(-40, 40, 3)), fovy=float(rng.uniform(30, 60)))
+            set_camera()
+        elif op == 3:                                                 # other settings
+            if rng.random() < 0.3:
+                cfg = cfg_uniform(int(rng.integers(1, 4)), max_depth=int(rng.integers(1, 5)))
+            else:
+                r_i = int(rng.integers(1, 25))
+                cfg = cfg_foveated(r_i, r_i + int(rng.integers(1, 40)), tuple(int(x) for x in rng.integers(1, 5, 3)), max_depth=int(rng.integers(1, 5)))
+            cfg.accumulate = int(rng.random() < 0.4)
+            r.config = cfg
+        elif op == 4:                                                 # the application resets the subframe counter
+            sub = int(rng.integers(0, 3))
+            for lp in (r.launchParams, F.lp):
+                lp.frame.subframe_index = sub
+        gaze = (int(rng.integers(0, size[0])), int(rng.integers(0, size[1])))
+        for lp in (r.launchParams, F.lp):
+            lp.frame.c.x, lp.frame.c.y = gaze
+        frames = int(rng.integers(1, 4))                              # several frames in flight before anyone looks
+        for _ in range(frames):
+            r.render_async()
+            oracle.render(S, F, cfg)
+        r.synchronize()
+        assert r.launchParams.frame.subframe_index == F.lp.frame.subframe_index, (seed, step, op, frames, bool(cfg.uniform))
+        assert _eq(r.downloadAccum(), F.accum) and np.array_equal(r.downloadPixels(), F.frame), (seed, step, op, size)
     r.close()
