@@ -194,6 +194,17 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     mrays = rays_total / elapsed / 1e6
 
+    # ---- latency of ONE frame (render() + synchronise, nothing else in flight): the timed loop above keeps
+    # frames back to back, so the tail of frame k overlaps the head of frame k+1 (two state sets)
+    lat_frames = max(5, min(50, args.steps))
+    r.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(lat_frames):
+        r.launchParams.frame.subframe_index = 0
+        r.render_async()
+        r.synchronize()
+    frame_latency_ms = (time.perf_counter() - t0) / lat_frames * 1e3
+
     # ---- roofline of the dominant kernel: separate profiled frames (hipEvents on the library's
     # own stream around every kernel; fovpt_stats accumulates them)
     cfg.profile = 1
@@ -245,6 +256,7 @@ def main():
     out = {
         "metric": "Mray/s", "value": round(mrays, 2), "unit": "Mray/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+        "frame_latency_ms": round(frame_latency_ms, 4),
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {
