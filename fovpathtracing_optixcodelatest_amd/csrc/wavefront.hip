@@ -832,7 +832,9 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
 // very different numbers of steps (SIMD utilisation 36 % with static rounds).  The pool is private to
 // the wave: no atomics.  (For closest-hit rays the same scheme was measured 10 % slower: the divergent
 // refill -- merge and store the hit, fetch, set up -- costs more than their better lane use returns.)
+#ifndef FOVPT_REFILL
 #define FOVPT_REFILL 6
+#endif
 __device__ inline void traverse_shadow_pool(const SceneView& sc, const PathState& ps, const ShadowQueue& sq, const ShardMap& map, uint32_t cap,
                                             uint32_t first, uint32_t end, int* __restrict__ stack, const QuadLane& q, unsigned long long* diag)
 {
