@@ -556,6 +556,14 @@ def test_random_scenes_and_materials(oracle, seed):
     size = (int(rng.integers(40, 120)), int(rng.integers(30, 90)))
     cfg = cfg_uniform(int(rng.integers(1, 4)), max_depth=int(rng.integers(1, 6)))
     probe = scenes.sky_probe() if seed % 2 else scenes.ambient_probe(32, 16, 1.0)
+    if seed % 5 == 4:
+        # a hostile environment map: black rows and columns (zero row sums: BuildCDF divides 0 by 0 exactly as
+        # the reference does), a few very bright texels
+        probe = rng.uniform(0, 1, (12, 24, 4)).astype(np.float32) ** 4
+        probe[..., 3] = 1.0
+        probe[int(rng.integers(0, 12))] = (0, 0, 0, 1)
+        probe[:, int(rng.integers(0, 24))] = (0, 0, 0, 1)
+        probe[int(rng.integers(0, 12)), int(rng.integers(0, 24)), :3] = 5000.0
     r = make_gpu(model, probe, cam, size, cfg)
     r.render()
     S, F = make_oracle(oracle, model, probe, cam, size)
