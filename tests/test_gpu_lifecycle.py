@@ -282,7 +282,10 @@ def test_random_lifecycle(oracle, seed):
             set_camera()
         elif op == 1:                                                 # other environment
             probe_data = (scenes.sky_probe(), scenes.ambient_probe(size[0], size[1], 2.5), scenes.ambient_probe(24, 12, 0.8))[int(rng.integers(0, 3))]
-            r.setProbe(renderer.ProbeData(probe_data).BuildCDF())
+            if rng.random() < 0.5:
+                r.setProbe(renderer.ProbeData(probe_data).BuildCDF())            # BuildCDF on the host (as the reference)
+            else:
+                r.setProbeData(probe_data)                                        # BuildCDF on the device
             hp = oracle.HostProbe(probe_data)
             F.probe = hp; F.lp.probe = hp.struct
         elif op == 2:                                                 # camera moved
