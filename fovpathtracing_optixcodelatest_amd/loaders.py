@@ -39,7 +39,7 @@ def _parse_mtl(path: str) -> Dict[str, dict]:
                 continue
             k = t[0]
             if k == "newmtl":
-                cur = {"Kd": (0.8, 0.8, 0.8) if False else None, "Ke": (0.0, 0.0, 0.0), "map_Kd": ""}
+                cur = {"Kd": None, "Ke": (0.0, 0.0, 0.0), "map_Kd": ""}
                 mats[" ".join(t[1:])] = cur
             elif cur is None:
                 continue
@@ -55,25 +55,258 @@ def _parse_mtl(path: str) -> Dict[str, dict]:
     return mats
 
 
+_ADAM7 = ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2))   # x0, y0, dx, dy
+
+
+def _png_unfilter(raw: memoryview, pos: int, rows: int, rowbytes: int, bpp: int) -> Tuple[np.ndarray, int]:
+    """Undo the per-scanline filters (PNG 1.2 section 6) of `rows` scanlines starting at raw[pos]."""
+    out = np.zeros((rows, rowbytes), np.uint8)
+    prev = np.zeros(rowbytes, np.uint8)
+    for y in range(rows):
+        ft = raw[pos]
+        line = np.frombuffer(raw[pos + 1:pos + 1 + rowbytes], np.uint8)
+        if len(line) != rowbytes:
+            raise ValueError("png: truncated image data")
+        pos += 1 + rowbytes
+        if ft == 0:
+            cur = line.copy()
+        elif ft == 1:                                            # Sub: a running sum per channel
+            cur = line.copy()
+            for c in range(bpp):
+                cur[c::bpp] = np.cumsum(line[c::bpp], dtype=np.uint64).astype(np.uint8)
+        elif ft == 2:                                            # Up
+            cur = line + prev
+        elif ft in (3, 4):                                       # Average, Paeth: sequential along the row
+            cur_l = [0] * rowbytes
+            ln, pv = line.tolist(), prev.tolist()
+            if ft == 3:
+                for i in range(rowbytes):
+                    a = cur_l[i - bpp] if i >= bpp else 0
+                    cur_l[i] = (ln[i] + ((a + pv[i]) >> 1)) & 255
+            else:
+                for i in range(rowbytes):
+                    a = cur_l[i - bpp] if i >= bpp else 0
+                    b = pv[i]
+                    c = pv[i - bpp] if i >= bpp else 0
+                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                    pr = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                    cur_l[i] = (ln[i] + pr) & 255
+            cur = np.array(cur_l, np.uint8)
+        else:
+            raise ValueError("png: bad filter type")
+        out[y] = cur
+        prev = cur
+    return out, pos
+
+
+def decode_png(data: bytes) -> np.ndarray:
+    """PNG -> (H, W, 4) uint8 as stbi_load(..., STBI_rgb_alpha) returns it (support/stb_image via
+    Model.cpp:106-107): all colour types, bit depths 1-16 (16-bit samples keep their high byte, gray
+    of 1/2/4 bits is scaled to 0..255), palette and tRNS transparency (a colour key gives alpha 0),
+    Adam7 interlacing; gamma and colour-profile chunks are ignored."""
+    import struct
+    import zlib
+    if data[:8] != b"\x89PNG\r\n\x1a\n":
+        raise ValueError("png: bad signature")
+    pos, idat, plte, trns, hdr = 8, [], None, None, None
+    while pos + 8 <= len(data):
+        n, kind = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        pos += 12 + n
+        if kind == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif kind == b"PLTE":
+            plte = np.frombuffer(body, np.uint8).reshape(-1, 3)
+        elif kind == b"tRNS":
+            trns = body
+        elif kind == b"IDAT":
+            idat.append(body)
+        elif kind == b"IEND":
+            break
+    if hdr is None or not idat:
+        raise ValueError("png: no header or no image data")
+    w, h, depth, ctype, comp, filt, interlace = hdr
+    if w == 0 or h == 0 or comp or filt or interlace > 1 or ctype not in (0, 2, 3, 4, 6) or depth not in (1, 2, 4, 8, 16):
+        raise ValueError("png: unsupported header")
+    if (ctype == 3 and depth == 16) or (ctype in (2, 4, 6) and depth < 8) or (ctype == 3 and plte is None):
+        raise ValueError("png: bad colour type / depth")
+    chans = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+    raw = memoryview(zlib.decompress(b"".join(idat)))
+    bpp = max(1, chans * depth // 8)
+
+    def samples(rows: np.ndarray, pw: int) -> np.ndarray:       # (ph, rowbytes) bytes -> (ph, pw, chans) uint16 samples
+        if depth == 8:
+            return rows.reshape(rows.shape[0], pw, chans).astype(np.uint16)
+        if depth == 16:
+            v = rows.reshape(rows.shape[0], pw, chans, 2).astype(np.uint16)
+            return (v[..., 0] << 8) | v[..., 1]
+        bits = np.unpackbits(rows, axis=1)[:, :pw * depth].reshape(rows.shape[0], pw, depth).astype(np.uint16)
+        return (bits << np.arange(depth - 1, -1, -1, dtype=np.uint16)).sum(axis=2, dtype=np.uint16)[..., None]
+
+    img = np.zeros((h, w, chans), np.uint16)
+    off = 0
+    if not interlace:
+        rows, off = _png_unfilter(raw, 0, h, (w * chans * depth + 7) // 8, bpp)
+        img[:] = samples(rows, w)
+    else:
+        for x0, y0, dx, dy in _ADAM7:
+            pw, ph = (w - x0 + dx - 1) // dx, (h - y0 + dy - 1) // dy
+            if pw <= 0 or ph <= 0:
+                continue
+            rows, off = _png_unfilter(raw, off, ph, (pw * chans * depth + 7) // 8, bpp)
+            img[y0::dy, x0::dx] = samples(rows, pw)
+
+    rgba = np.empty((h, w, 4), np.uint8)
+    if ctype == 3:
+        idx = img[..., 0]
+        plte = np.concatenate([plte[:256], np.zeros((256 - min(len(plte), 256), 3), np.uint8)])   # an index past the palette reads black
+        alpha = np.full(256, 255, np.uint8)
+        if trns is not None:
+            alpha[:min(len(trns), 256)] = np.frombuffer(trns, np.uint8)[:256]
+        rgba[..., :3] = plte[idx]
+        rgba[..., 3] = alpha[idx]
+        return rgba
+    keyed = None
+    if trns is not None and ctype in (0, 2):                    # colour key, compared at the file's precision
+        key = np.frombuffer(trns[:len(trns) & ~1], ">u2")[:chans].astype(np.uint16)
+        if depth <= 8:
+            key &= 255                                           # stb keeps the low byte of an 8-bit key
+        if len(key) == chans:
+            keyed = np.all(img == key, axis=2)
+    if depth == 16:
+        v = (img >> 8).astype(np.uint8)
+    elif depth == 8:
+        v = img.astype(np.uint8)
+    else:
+        v = (img * {1: 255, 2: 85, 4: 17}[depth]).astype(np.uint8)
+    if ctype in (0, 4):
+        rgba[..., 0] = rgba[..., 1] = rgba[..., 2] = v[..., 0]
+        rgba[..., 3] = v[..., 1] if ctype == 4 else 255
+    else:
+        rgba[..., :3] = v[..., :3]
+        rgba[..., 3] = v[..., 3] if ctype == 6 else 255
+    if keyed is not None:
+        rgba[..., 3] = np.where(keyed, 0, 255)
+    return rgba
+
+
+def decode_tga(data: bytes) -> np.ndarray:
+    """Truevision TGA -> (H, W, 4) uint8 the way stb_image reads it: image types 1/2/3 and their RLE forms
+    9/10/11; 8 (gray or index), 15/16 (5-5-5), 24 and 32 bits; rows bottom-up unless descriptor bit 5 is set."""
+    import struct
+    if len(data) < 18:
+        raise ValueError("tga: truncated header")
+    idlen, cmap_type, itype, cm_first, cm_len, cm_bits, _x0, _y0, w, h, bits, desc = struct.unpack("<BBBHHBHHHHBB", data[:18])
+    rle = itype >= 8
+    base = itype & 7
+    if base not in (1, 2, 3) or w == 0 or h == 0 or cmap_type > 1 or (base == 1) != (cmap_type == 1):
+        raise ValueError("tga: unsupported image type")
+    if base == 1 and bits not in (8, 16) or base == 3 and bits not in (8, 16) or base == 2 and bits not in (15, 16, 24, 32):
+        raise ValueError("tga: unsupported pixel depth")
+    pos = 18 + idlen
+
+    def expand(px: np.ndarray, nbits: int, gray: bool) -> np.ndarray:   # (n, bytes) -> (n, 4) RGBA
+        n = px.shape[0]
+        out = np.full((n, 4), 255, np.uint8)
+        if nbits == 8:
+            out[:, 0] = out[:, 1] = out[:, 2] = px[:, 0]
+        elif nbits in (15, 16) and gray:                       # gray + alpha
+            out[:, 0] = out[:, 1] = out[:, 2] = px[:, 0]
+            out[:, 3] = px[:, 1]
+        elif nbits in (15, 16):                                # 5-5-5, top bit ignored
+            v = px[:, 0].astype(np.uint32) | (px[:, 1].astype(np.uint32) << 8)
+            for c, sh in ((0, 10), (1, 5), (2, 0)):
+                out[:, c] = (((v >> sh) & 31) * 255 // 31).astype(np.uint8)
+        else:
+            out[:, 0], out[:, 1], out[:, 2] = px[:, 2], px[:, 1], px[:, 0]
+            if nbits == 32:
+                out[:, 3] = px[:, 3]
+        return out
+
+    palette = None
+    if cmap_type:
+        if cm_bits not in (8, 15, 16, 24, 32):
+            raise ValueError("tga: unsupported palette depth")
+        eb = (cm_bits + 7) // 8
+        pos += cm_first                                         # stb skips "first entry index" BYTES, then reads cm_len entries
+        pal = np.frombuffer(data[pos:pos + cm_len * eb], np.uint8)
+        if len(pal) != cm_len * eb:
+            raise ValueError("tga: truncated palette")
+        pos += cm_len * eb
+        if base == 1:
+            palette = expand(pal.reshape(cm_len, eb), cm_bits, False)
+    nb = (bits + 7) // 8
+    n = w * h
+    if not rle:
+        px = np.frombuffer(data[pos:pos + n * nb], np.uint8)
+        if len(px) != n * nb:
+            raise ValueError("tga: truncated image data")
+        px = px.reshape(n, nb)
+    else:
+        chunks, got = [], 0
+        while got < n:
+            if pos >= len(data):
+                raise ValueError("tga: truncated RLE data")
+            c = data[pos]
+            cnt = (c & 127) + 1
+            pos += 1
+            if c & 128:
+                one = np.frombuffer(data[pos:pos + nb], np.uint8)
+                if len(one) != nb:
+                    raise ValueError("tga: truncated RLE data")
+                chunks.append(np.tile(one, (cnt, 1)))
+                pos += nb
+            else:
+                lit = np.frombuffer(data[pos:pos + cnt * nb], np.uint8)
+                if len(lit) != cnt * nb:
+                    raise ValueError("tga: truncated RLE data")
+                chunks.append(lit.reshape(cnt, nb))
+                pos += cnt * nb
+            got += cnt
+        px = np.concatenate(chunks)[:n]
+    if base == 1:
+        idx = px[:, 0].astype(np.int64) if nb == 1 else (px[:, 0].astype(np.int64) | (px[:, 1].astype(np.int64) << 8))
+        idx = np.where(idx >= cm_len, 0, idx)                   # stb: an index outside the palette reads entry 0
+        rgba = palette[idx]
+    else:
+        rgba = expand(px, bits, base == 3)
+    rgba = rgba.reshape(h, w, 4)
+    if not (desc >> 5) & 1:                                     # bottom-left origin: stb hands rows back top-down
+        rgba = rgba[::-1]
+    return np.ascontiguousarray(rgba)
+
+
+def _decode_ppm(data: bytes) -> np.ndarray:
+    toks: List[bytes] = []
+    pos = 0
+    while len(toks) < 4:
+        end = data.find(b"\n", pos)
+        if end < 0:
+            raise ValueError("ppm: truncated header")
+        toks += data[pos:end].split(b"#", 1)[0].split()
+        pos = end + 1
+    w, h, mx = int(toks[1]), int(toks[2]), int(toks[3])
+    if toks[0] != b"P6" or mx != 255:
+        raise ValueError("ppm: only binary 8-bit P6")
+    rgb = np.frombuffer(data[pos:pos + w * h * 3], np.uint8).reshape(h, w, 3)
+    return np.concatenate([rgb, np.full((h, w, 1), 255, np.uint8)], axis=2)
+
+
 def _load_texture(path: str) -> Optional[np.ndarray]:
-    """RGBA8 as (H, W) uint32, mirrored along y (Model.cpp:117-126).  Needs Pillow for PNG/JPG/TGA;
-    binary PPM (P6) is read natively."""
+    """RGBA8 as (H, W) uint32, mirrored along y (Model.cpp:117-126).  PNG, TGA and binary PPM are decoded
+    here; JPEG and the rarer formats stb_image knows go through Pillow when it is installed, otherwise
+    they count as "could not load" (texture id -1, Model.cpp:129-131)."""
     if not os.path.exists(path):
         return None
     try:
         with open(path, "rb") as f:
-            head = f.read(2)
-        if head == b"P6":
-            with open(path, "rb") as f:
-                toks: List[bytes] = []
-                while len(toks) < 4:
-                    line = f.readline()
-                    if not line:
-                        return None
-                    toks += line.split(b"#", 1)[0].split()
-                w, h, mx = int(toks[1]), int(toks[2]), int(toks[3])
-                rgb = np.frombuffer(f.read(w * h * 3), np.uint8).reshape(h, w, 3)
-            rgba = np.concatenate([rgb, np.full((h, w, 1), 255, np.uint8)], axis=2)
+            data = f.read()
+        if data[:8] == b"\x89PNG\r\n\x1a\n":
+            rgba = decode_png(data)
+        elif data[:2] == b"P6":
+            rgba = _decode_ppm(data)
+        elif path.lower().endswith(".tga"):
+            rgba = decode_tga(data)
         else:
             from PIL import Image                          # optional dependency
             rgba = np.asarray(Image.open(path).convert("RGBA"), np.uint8)

@@ -81,3 +81,76 @@ def encode_hdr_rle(texels_rgbe, comments=("# written by tests/common.py",), magi
                     out += bytes([n]) + bytes(row[i:i + n].tolist())
                     i += n
     return bytes(out)
+
+
+def encode_png(samples: np.ndarray, depth: int, ctype: int, filters=(0, 1, 2, 3, 4), interlace: bool = False,
+               plte: bytes = None, trns: bytes = None) -> bytes:
+    """A small PNG writer for loader tests: samples (H, W, C) integers of `depth` bits, every scanline
+    filtered with the next entry of `filters` (so each filter type is exercised), optional Adam7."""
+    import struct
+    import zlib
+    h, w, chans = samples.shape
+    bpp = max(1, chans * depth // 8)
+
+    def pack(block: np.ndarray) -> list:                         # (ph, pw, C) -> list of byte rows
+        rows = []
+        for r in block:
+            flat = r.reshape(-1).astype(np.uint32)
+            if depth == 8:
+                rows.append(flat.astype(np.uint8).tolist())
+            elif depth == 16:
+                rows.append(np.stack([flat >> 8, flat & 255], axis=1).reshape(-1).astype(np.uint8).tolist())
+            else:
+                bits = ((flat[:, None] >> np.arange(depth - 1, -1, -1)) & 1).reshape(-1).astype(np.uint8)
+                rows.append(np.packbits(bits).tolist())
+        return rows
+
+    counter = [0]
+
+    def filtered(rows: list) -> bytes:
+        out = bytearray()
+        prev = [0] * (len(rows[0]) if rows else 0)
+        for cur in rows:
+            ft = filters[counter[0] % len(filters)]
+            counter[0] += 1
+            out.append(ft)
+            for i, x in enumerate(cur):
+                a = cur[i - bpp] if i >= bpp else 0
+                b = prev[i]
+                c = prev[i - bpp] if i >= bpp else 0
+                if ft == 0:
+                    p = 0
+                elif ft == 1:
+                    p = a
+                elif ft == 2:
+                    p = b
+                elif ft == 3:
+                    p = (a + b) >> 1
+                else:
+                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                    p = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                out.append((x - p) & 255)
+            prev = cur
+        return bytes(out)
+
+    if interlace:
+        body = b""
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = samples[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                body += filtered(pack(sub))
+    else:
+        body = filtered(pack(samples))
+
+    def chunk(kind: bytes, payload: bytes) -> bytes:
+        return struct.pack(">I", len(payload)) + kind + payload + struct.pack(">I", zlib.crc32(kind + payload))
+
+    z = zlib.compress(body)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1 if interlace else 0))
+    out += chunk(b"gAMA", struct.pack(">I", 45455))              # ignored by stb_image
+    if plte is not None:
+        out += chunk(b"PLTE", plte)
+    if trns is not None:
+        out += chunk(b"tRNS", trns)
+    half = len(z) // 2
+    return out + chunk(b"IDAT", z[:half]) + chunk(b"IDAT", z[half:]) + chunk(b"IEND", b"")

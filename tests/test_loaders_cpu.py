@@ -229,3 +229,136 @@ def test_gltf_model_packs_for_the_c_abi(tmp_path):
     path, _ = _gltf_fixture(tmp_path)
     md, n, td, nt, keep = scenes.pack_model(loaders.load_gltf(path))
     assert n == 2 and nt == 0 and md[0].num_triangles == 2 and md[1].num_triangles == 1 and md[0].texture_id == -1
+
+
+# ---- texture decoders (what stbi_load(..., STBI_rgb_alpha) hands to Model.cpp:106-107) ------------------------------
+
+def _to_rgba(samples, depth, ctype, plte=None, trns=None):
+    """Expected RGBA8 for encode_png's input, from the rules of stb_image."""
+    h, w, _ = samples.shape
+    out = np.full((h, w, 4), 255, np.uint8)
+    if ctype == 3:
+        pal = np.frombuffer(plte, np.uint8).reshape(-1, 3)
+        out[..., :3] = pal[samples[..., 0]]
+        if trns is not None:
+            al = np.full(len(pal), 255, np.uint8)
+            al[:len(trns)] = np.frombuffer(trns, np.uint8)
+            out[..., 3] = al[samples[..., 0]]
+        return out
+    v = samples.astype(np.uint32)
+    v8 = (v >> 8 if depth == 16 else v * {1: 255, 2: 85, 4: 17, 8: 1}[depth]).astype(np.uint8)
+    if ctype in (0, 4):
+        out[..., 0] = out[..., 1] = out[..., 2] = v8[..., 0]
+        if ctype == 4:
+            out[..., 3] = v8[..., 1]
+    else:
+        out[..., :3] = v8[..., :3]
+        if ctype == 6:
+            out[..., 3] = v8[..., 3]
+    if trns is not None:
+        key = np.frombuffer(trns, ">u2").astype(np.uint32)
+        out[..., 3] = np.where(np.all(v == key, axis=2), 0, 255)
+    return out
+
+
+@pytest.mark.parametrize("interlace", [False, True])
+def test_png_decoder_all_colour_types_depths_and_filters(interlace):
+    from tests.common import encode_png
+    rng = np.random.default_rng(11)
+    cases = [(0, d) for d in (1, 2, 4, 8, 16)] + [(2, 8), (2, 16), (3, 1), (3, 2), (3, 4), (3, 8), (4, 8), (4, 16), (6, 8), (6, 16)]
+    for ctype, depth in cases:
+        chans = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[ctype]
+        for (w, h) in ((13, 9), (1, 1), (8, 8), (3, 17)):
+            plte = trns = None
+            hi = 1 << depth
+            if ctype == 3:
+                n = min(hi, 200)
+                plte = rng.integers(0, 256, n * 3, dtype=np.uint8).tobytes()
+                hi = n
+                trns = rng.integers(0, 256, n // 2 + 1, dtype=np.uint8).tobytes() if w > 1 else None
+            s = rng.integers(0, hi, (h, w, chans)).astype(np.uint16)
+            if ctype in (0, 2) and w == 13:                          # a colour key that occurs in the image
+                trns = b"".join(int(x).to_bytes(2, "big") for x in s[h // 2, w // 2])
+            got = loaders.decode_png(encode_png(s, depth, ctype, interlace=interlace, plte=plte, trns=trns))
+            assert np.array_equal(got, _to_rgba(s, depth, ctype, plte, trns)), (ctype, depth, w, h)
+
+
+def test_png_decoder_rejects_malformed_files():
+    from tests.common import encode_png
+    s = np.arange(5 * 4 * 3).reshape(4, 5, 3).astype(np.uint16)
+    good = encode_png(s, 8, 2)
+    assert loaders.decode_png(good).shape == (4, 5, 4)
+    for bad in (good[:40], b"\x00" + good[1:], good.replace(b"IDAT", b"iDAT"), good[:16] + b"\x00\x00\x00\x00" + good[20:]):
+        with pytest.raises(Exception):
+            loaders.decode_png(bad)
+
+
+def _tga(w, h, itype, bits, px_bytes, desc=0, cmap=b"", cm_len=0, cm_bits=0, idfield=b"id"):
+    import struct
+    return struct.pack("<BBBHHBHHHHBB", len(idfield), 1 if cmap else 0, itype, 0, cm_len, cm_bits, 0, 0, w, h, bits, desc) + idfield + cmap + px_bytes
+
+
+def _rle(px: np.ndarray) -> bytes:                                # (n, nb) -> alternating run / literal packets
+    out, i, n = bytearray(), 0, len(px)
+    toggle = True
+    while i < n:
+        cnt = min(n - i, 3 if toggle else 5)
+        if toggle:
+            px[i:i + cnt] = px[i]
+            out += bytes([128 | (cnt - 1)]) + px[i].tobytes()
+        else:
+            out += bytes([cnt - 1]) + px[i:i + cnt].tobytes()
+        i += cnt
+        toggle = not toggle
+    return bytes(out)
+
+
+def test_tga_decoder_truecolour_gray_palette_and_rle():
+    rng = np.random.default_rng(5)
+    w, h = 7, 5
+    for bits, rle, top in ((24, False, False), (32, False, True), (24, True, False), (32, True, True)):
+        px = rng.integers(0, 256, (w * h, bits // 8), dtype=np.uint8)
+        body = _rle(px) if rle else px.tobytes()
+        got = loaders.decode_tga(_tga(w, h, 10 if rle else 2, bits, body, desc=0x20 if top else 0))
+        exp = np.full((w * h, 4), 255, np.uint8)
+        exp[:, 0], exp[:, 1], exp[:, 2] = px[:, 2], px[:, 1], px[:, 0]
+        if bits == 32:
+            exp[:, 3] = px[:, 3]
+        exp = exp.reshape(h, w, 4)
+        assert np.array_equal(got, exp if top else exp[::-1])
+    g = rng.integers(0, 256, (w * h, 1), dtype=np.uint8)
+    got = loaders.decode_tga(_tga(w, h, 11, 8, _rle(g), desc=0x20))
+    assert np.array_equal(got[..., 0].reshape(-1), g[:, 0]) and np.all(got[..., 3] == 255) and np.array_equal(got[..., 0], got[..., 2])
+    v = rng.integers(0, 1 << 15, w * h).astype(np.uint16)          # 5-5-5
+    got = loaders.decode_tga(_tga(w, h, 2, 16, v.astype("<u2").tobytes(), desc=0x20)).reshape(-1, 4)
+    assert np.array_equal(got[:, 0], ((v >> 10) & 31).astype(np.uint32) * 255 // 31)
+    assert np.array_equal(got[:, 2], (v & 31).astype(np.uint32) * 255 // 31)
+    pal = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    idx = rng.integers(0, 20, (w * h, 1), dtype=np.uint8)           # indices 16..19 fall back to entry 0
+    got = loaders.decode_tga(_tga(w, h, 1, 8, idx.tobytes(), desc=0x20, cmap=pal.tobytes(), cm_len=16, cm_bits=24)).reshape(-1, 4)
+    e = pal[np.where(idx[:, 0] >= 16, 0, idx[:, 0])]
+    assert np.array_equal(got[:, 0], e[:, 2]) and np.array_equal(got[:, 2], e[:, 0]) and np.array_equal(got[:, 1], e[:, 1])
+    for bad in (b"", _tga(w, h, 2, 24, b"\x00" * 10), _tga(w, h, 4, 24, b"\x00" * 200), _tga(w, h, 10, 24, b"\x85\x01")):
+        with pytest.raises(Exception):
+            loaders.decode_tga(bad)
+
+
+def test_obj_with_png_and_tga_textures(tmp_path):
+    from tests.common import encode_png
+    rng = np.random.default_rng(3)
+    s = rng.integers(0, 256, (6, 4, 4)).astype(np.uint16)
+    (tmp_path / "a.png").write_bytes(encode_png(s, 8, 6))
+    t = rng.integers(0, 256, (6 * 4, 3), dtype=np.uint8)
+    (tmp_path / "b.tga").write_bytes(_tga(4, 6, 2, 24, t.tobytes()))
+    (tmp_path / "m.mtl").write_text("newmtl A\nKd 1 1 1\nmap_Kd a.png\nnewmtl B\nKd 1 1 1\nmap_Kd b.tga\nnewmtl C\nKd 1 1 1\nmap_Kd missing.jpg\n")
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\n"
+                                    "usemtl A\nf 1/1 2/2 3/3\nusemtl B\nf 1/1 2/2 3/3\nusemtl C\nf 1/1 2/2 3/3\n")
+    model = loaders.load_obj(str(tmp_path / "m.obj"))
+    ids = [m.texture_id for m in model.meshes]
+    assert ids == [0, 1, -1]
+    px = model.textures[0]
+    r = s[::-1].astype(np.uint32)                                    # mirrored along y (Model.cpp:117-126)
+    assert np.array_equal(px, r[..., 0] | (r[..., 1] << 8) | (r[..., 2] << 16) | (r[..., 3] << 24))
+    tb = t.reshape(6, 4, 3).astype(np.uint32)                        # bottom-up file -> stb flips -> Model.cpp mirrors back
+    px = model.textures[1]
+    assert np.array_equal(px, tb[..., 2] | (tb[..., 1] << 8) | (tb[..., 0] << 16) | (255 << 24))
