@@ -40,12 +40,38 @@ def build(force=False):
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's, found by file name
+    through an RPATH).  Imported FIRST, torch's copy also serves libfovpt.so; imported AFTER libfovpt.so has
+    pulled in /opt/rocm's copy, torch loads a second HIP/HSA runtime into the process, which finds "No HIP
+    GPUs".  So when torch is installed but not imported yet, its copy is loaded here, and either import order
+    ends with one runtime.  Without torch (C++ callers, plain Python) the library binds to /opt/rocm as linked.
+    FOVPT_SYSTEM_HIP=1 skips this."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("FOVPT_SYSTEM_HIP"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    hip = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(hip):
+        try:
+            C.CDLL(hip, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load():
     global _lib
     if _lib is not None:
         return _lib
     if not os.path.exists(SO_PATH):
         raise FovptError(-100, "%s is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950)" % SO_PATH)
+    _share_torch_hip_runtime()
     L = C.CDLL(SO_PATH)
     vp, i32, u32, u64, sz = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_size_t
     L.fovpt_create.argtypes = [C.POINTER(vp), i32]

@@ -315,3 +315,22 @@ def test_random_lifecycle(oracle, seed):
         assert r.launchParams.frame.subframe_index == F.lp.frame.subframe_index, (seed, step, op, frames, bool(cfg.uniform))
         assert _eq(r.downloadAccum(), F.accum) and np.array_equal(r.downloadPixels(), F.frame), (seed, step, op, size)
     r.close()
+
+
+@pytest.mark.gpu
+def test_library_and_torch_share_one_hip_runtime_in_either_import_order():
+    """libfovpt.so first and torch afterwards used to leave torch with "No HIP GPUs are available" (two HIP
+    runtimes in one process, see lib._share_torch_hip_runtime); both orders must work."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    body = ("from fovpathtracing_optixcodelatest_amd import renderer, scenes\n"
+            "def lib_part():\n"
+            "    r = renderer.SampleRenderer(scenes.cornell_box()); r.resize((64, 64)); cam = scenes.CORNELL_CAMERA\n"
+            "    r.setCamera(renderer.Camera(cam['eye'], cam['lookat'], cam['up'], cam['fovy'], 1.0))\n"
+            "    r.setProbe(renderer.ProbeData(scenes.ambient_probe(64, 32, 0.2)).BuildCDF()); r.render(); return int(r.downloadPixels().sum())\n"
+            "def torch_part():\n"
+            "    import torch; return int(torch.arange(10, device='cuda').sum().item())\n")
+    for order in ("a = lib_part(); b = torch_part()", "b = torch_part(); a = lib_part()"):
+        out = subprocess.run([sys.executable, "-c", body + order + "\nprint('ok', a > 0, b)"], cwd=root, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "ok True 45" in out.stdout, (order, out.stdout[-500:], out.stderr[-1500:])
