@@ -124,8 +124,8 @@ def main():
     sync_gather = rehearsal
     step_no = [0]
 
-    # torch's view of the library's main stream: collectives issued under it are ordered after the
-    # frame on the device, so the loop needs no host synchronisation (the host runs ahead)
+    # torch's view of the stream on which the library's frames complete (fovpt_stream()): collectives issued
+    # under it are ordered after the frame on the device, so the loop needs no host synchronisation
     lib_stream = torch.cuda.ExternalStream(r.stream, device=torch.device("cuda", local_rank))
 
     def step():
