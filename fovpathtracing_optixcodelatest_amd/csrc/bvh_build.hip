@@ -189,7 +189,9 @@ __global__ void k_iota(uint32_t* v, uint32_t n)
 // round every cluster looks FOVPT_PLOC_RADIUS neighbours left and right along the Morton curve for
 // the partner that minimises the surface area of the merged box; mutual choices merge.
 // ------------------------------------------------------------------------------------------
+#ifndef FOVPT_PLOC_RADIUS
 #define FOVPT_PLOC_RADIUS 16
+#endif
 
 __device__ inline float union_area(const Box& a, const Box& b)
 {
@@ -300,6 +302,64 @@ __device__ inline float box_area(const Box& b)
     return dx * dy + dy * dz + dz * dx;
 }
 
+// ---- cost-optimal 2 -> 4 collapse (the dynamic programme of Ylitie et al. 2017 for wide BVHs) -------------------
+// C(x, i) = cheapest way to present the binary subtree x to a wide parent in at most i of its child slots:
+//   C(x, 1) = min( area(x) * COST_LEAF                                    if x holds <= FOVPT_LEAF_MAX triangles,
+//                  area(x) * 1 + min_k C(left, k) + C(right, 4 - k) )     x becomes a wide node
+//   C(x, i) = min( C(x, i-1), min_k C(left, k) + C(right, i - k) )        x dissolves into its parent
+// in units of node steps (a leaf step costs the traversal kernel about 2.7 of them).  Computed bottom-up,
+// the second thread to arrive at a node does the work (as in k_refit); the decisions steer k_collapse4.
+#ifndef FOVPT_V_DPCOLLAPSE
+#define FOVPT_V_DPCOLLAPSE 1
+#endif
+#ifndef FOVPT_COST_LEAF
+#define FOVPT_COST_LEAF 2.7f
+#endif
+struct DpCost {
+    float c1, c2, c3;
+    uint32_t dec;       // bits 0-1: slots for the left child when x is a wide node; 2: x is a leaf; 3: two slots = (1, 1);
+};                      // bits 4-5: three slots = 0 as for two, 1 (1, 2), 2 (2, 1)
+
+__device__ inline void dp_child(int x, const Box* __restrict__ boxes, const uint32_t* __restrict__ vals, const volatile DpCost* dp,
+                                float& a1, float& a2, float& a3)
+{
+    if (x < 0) { a1 = a2 = a3 = box_area(boxes[vals[~x]]) * FOVPT_COST_LEAF; }
+    else { a1 = dp[x].c1; a2 = dp[x].c2; a3 = dp[x].c3; }
+}
+
+__global__ void k_dp_collapse(int n, const Box* __restrict__ boxes, const uint32_t* __restrict__ vals, const int* __restrict__ left,
+                              const int* __restrict__ right, const int* __restrict__ parent_int, const int* __restrict__ parent_leaf,
+                              const uint32_t* __restrict__ size_int, const Box* __restrict__ ibox, DpCost* dp, uint32_t* __restrict__ arrive)
+{
+    int leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >= n) return;
+    int node = parent_leaf[leaf];
+    while (node >= 0) {
+        __threadfence();
+        if (atomicAdd(&arrive[node], 1u) == 0u) return;   // first arrival: the sibling's costs are not there yet
+        __threadfence();
+        float l1, l2, l3, r1, r2, r3;
+        dp_child(left[node], boxes, vals, dp, l1, l2, l3);
+        dp_child(right[node], boxes, vals, dp, r1, r2, r3);
+        float s = l1 + r3;
+        uint32_t dec = 1u;
+        if (l2 + r2 < s) { s = l2 + r2; dec = 2u; }
+        if (l3 + r1 < s) { s = l3 + r1; dec = 3u; }
+        const float area = box_area(ibox[node]);
+        float c1 = area + s;
+        if (size_int[node] <= FOVPT_LEAF_MAX && area * FOVPT_COST_LEAF <= c1) { c1 = area * FOVPT_COST_LEAF; dec |= 4u; }
+        float c2 = c1;
+        if (l1 + r1 < c2) { c2 = l1 + r1; dec |= 8u; }
+        float c3 = c2;
+        uint32_t d3 = 0u;
+        if (l1 + r2 < c3) { c3 = l1 + r2; d3 = 1u; }
+        if (l2 + r1 < c3) { c3 = l2 + r1; d3 = 2u; }
+        DpCost out; out.c1 = c1; out.c2 = c2; out.c3 = c3; out.dec = dec | (d3 << 4);
+        dp[node].c1 = out.c1; dp[node].c2 = out.c2; dp[node].c3 = out.c3; dp[node].dec = out.dec;
+        node = parent_int[node];
+    }
+}
+
 // One level of the top-down 2 -> 4 collapse: every work item is a binary node that becomes a wide node.
 // Its two children are expanded (largest surface area first) until four slots are used or nothing is
 // left to expand; children that stay internal are queued for the next level.
@@ -307,12 +367,37 @@ __global__ void k_collapse4(int nwork, const Work4* __restrict__ work_in, Work4*
                             const int* __restrict__ left, const int* __restrict__ right, const uint32_t* __restrict__ size_int,
                             const uint32_t* __restrict__ node_first, const uint32_t* __restrict__ leaf_pos,
                             const Box* __restrict__ boxes, const uint32_t* __restrict__ vals, const Box* __restrict__ ibox,
-                            BvhNode4* __restrict__ nodes, uint32_t* __restrict__ stats)
+                            const DpCost* __restrict__ dp, BvhNode4* __restrict__ nodes, uint32_t* __restrict__ stats)
 {
     int w = blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= nwork) return;
     const Work4 me = work_in[w];
     int ch[4];
+#if FOVPT_V_DPCOLLAPSE
+    // the children the dynamic programme chose: (subtree, slots) pairs are split until every pair fills one slot
+    int nch = 0;
+    {
+        int sn[4], ss[4], sp = 0;
+        const int k = (int)(dp[me.node].dec & 3u);
+        sn[sp] = right[me.node]; ss[sp++] = 4 - k;
+        sn[sp] = left[me.node]; ss[sp++] = k;
+        while (sp > 0) {
+            const int y = sn[--sp];
+            int sl = ss[sp];
+            if (y < 0 || sl == 1) { ch[nch++] = y; continue; }
+            const uint32_t d = dp[y].dec;
+            if (sl == 3) {
+                const uint32_t d3 = (d >> 4) & 3u;
+                if (d3 == 1u) { sn[sp] = right[y]; ss[sp++] = 2; sn[sp] = left[y]; ss[sp++] = 1; continue; }
+                if (d3 == 2u) { sn[sp] = right[y]; ss[sp++] = 1; sn[sp] = left[y]; ss[sp++] = 2; continue; }
+                sl = 2;
+            }
+            if (d & 8u) { sn[sp] = right[y]; ss[sp++] = 1; sn[sp] = left[y]; ss[sp++] = 1; }
+            else ch[nch++] = y;
+        }
+    }
+#else
+    // greedy: the two children are expanded, largest surface area first, until four slots are used
     int nch = 2;
     ch[0] = left[me.node]; ch[1] = right[me.node];
     for (;;) {
@@ -330,6 +415,7 @@ __global__ void k_collapse4(int nwork, const Work4* __restrict__ work_in, Work4*
         ch[pick] = left[x];
         ch[nch++] = right[x];
     }
+#endif
     BvhNode4 nd;
     for (int k = 0; k < 4; k++) {
         BvhChild& C = nd.c[k];
@@ -344,7 +430,11 @@ __global__ void k_collapse4(int nwork, const Work4* __restrict__ work_in, Work4*
         if (x < 0) { b = boxes[vals[~x]]; code = leaf_code((int)leaf_pos[~x], 1); }
         else {
             b = ibox[x];
+#if FOVPT_V_DPCOLLAPSE
+            if (dp[x].dec & 4u) code = leaf_code((int)node_first[x], (int)size_int[x]);
+#else
             if (size_int[x] <= FOVPT_LEAF_MAX) code = leaf_code((int)node_first[x], (int)size_int[x]);
+#endif
             else {
                 const uint32_t slot = atomicAdd(&counters[0], 1u);          // next free wide node
                 const uint32_t q = atomicAdd(&counters[1], 1u);             // next level's queue
@@ -421,6 +511,8 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
     size_t scan_bytes = 0;
     // collapse state
     Work4 *work_a = nullptr, *work_b = nullptr;
+    DpCost* dp = nullptr;
+    uint32_t* dp_arrive = nullptr;
     uint32_t* counters = nullptr;
     BvhNode4* nodes = nullptr;
     TriRec* tris = nullptr;
@@ -501,7 +593,11 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
                                leaf_pos, node_first, node_depth);
             root = (int)n - 2;                                 // the last merge created the root
         }
-        // ---- 2 -> 4 collapse, one launch per level of the wide tree
+        // ---- 2 -> 4 collapse: costs bottom-up, then one launch per level of the wide tree
+        HC(hipMalloc(&dp, sizeof(DpCost) * ni)); HC(hipMalloc(&dp_arrive, 4ull * ni));
+        HC(hipMemsetAsync(dp_arrive, 0, 4ull * ni, st));
+        hipLaunchKernelGGL(k_dp_collapse, dim3(gn), dim3(B), 0, st, (int)n, boxes, vals_s, left, right, parent_int, parent_leaf, size_int, ibox,
+                           dp, dp_arrive);
         HC(hipMalloc(&work_a, sizeof(Work4) * ni)); HC(hipMalloc(&work_b, sizeof(Work4) * ni));
         Work4 w0; w0.node = root; w0.out = 0; w0.depth = 0;
         HC(hipMemcpyAsync(work_a, &w0, sizeof(w0), hipMemcpyHostToDevice, st));
@@ -510,7 +606,7 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
         int levels = 0;
         while (nwork > 0) {
             hipLaunchKernelGGL(k_collapse4, dim3((nwork + B - 1) / B), dim3(B), 0, st, (int)nwork, work_a, work_b, counters, left, right,
-                               size_int, node_first, leaf_pos, boxes, vals_s, ibox, nodes, stats);
+                               size_int, node_first, leaf_pos, boxes, vals_s, ibox, dp, nodes, stats);
             HC(hipMemcpyAsync(h_counters, counters, 8, hipMemcpyDeviceToHost, st));
             HC(hipStreamSynchronize(st));
             nwork = h_counters[1];
@@ -538,6 +634,7 @@ fail:
     (void)hipFree(parent_leaf); (void)hipFree(rfirst); (void)hipFree(rlast); (void)hipFree(temp); (void)hipFree(nodes); (void)hipFree(tris);
     (void)hipFree(c_node); (void)hipFree(t_node); (void)hipFree(nn); (void)hipFree(c_box); (void)hipFree(t_box); (void)hipFree(valid); (void)hipFree(pos);
     (void)hipFree(node_counter); (void)hipFree(size_int); (void)hipFree(leaf_pos); (void)hipFree(node_first); (void)hipFree(node_depth);
+    (void)hipFree(dp); (void)hipFree(dp_arrive);
     (void)hipFree(side_int); (void)hipFree(side_leaf); (void)hipFree(scan_temp); (void)hipFree(work_a); (void)hipFree(work_b); (void)hipFree(counters);
     return rc;
 }

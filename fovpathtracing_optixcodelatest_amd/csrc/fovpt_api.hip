@@ -891,6 +891,7 @@ int fovpt_camera_uvw(const fovpt_float3* eye, const fovpt_float3* lookat, const 
 int fovpt_debug_buffer(fovpt_ctx* c, const char* name, void** ptr, size_t* bytes)
 {
     if (!c || !name || !ptr || !bytes) return FOVPT_E_INVALID;
+    if (strcmp(name, "bvh_nodes") == 0 && c->has_scene) { *ptr = c->nodes; *bytes = (size_t)c->stats.bvh_bytes; return FOVPT_OK; }   // tools/bvhstat.py
     StateSet& S = c->set[(c->jobs + 1u) & 1u];            // the set the most recent job used
     struct { const char* n; DevBuf* b; } tab[] = {
         {"sq_o", &S.sq_o[0]}, {"sq_d", &S.sq_d[0]}, {"sq_vis", &S.sq_vis[0]}, {"sq_occ", &S.sq_occ[0]}, {"counters", &S.counters},

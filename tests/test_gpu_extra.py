@@ -387,6 +387,26 @@ def test_small_geometry_seen_from_far_away(oracle):
         r.close()
 
 
+@pytest.mark.gpu
+def test_hierarchy_choice_does_not_change_the_frame(oracle, monkeypatch):
+    """Hits are defined without reference to the hierarchy (closest t, lowest primitive id): the plain Karras
+    LBVH (FOVPT_BVH=lbvh, the A/B path of fovpt_set_scene) must give the oracle's frame just as PLOC does."""
+    model = scenes.atrium(20000)
+    probe = scenes.sky_probe(64, 32, seed=3)
+    size, cfg = (320, 180), cfg_foveated(24, 80, (1, 2, 8))
+    S, F = make_oracle(oracle, model, probe, scenes.ATRIUM_CAMERA, size)
+    oracle.render(S, F, cfg)
+    nodes = {}
+    for kind in ("ploc", "lbvh"):
+        monkeypatch.setenv("FOVPT_BVH", kind)
+        r = make_gpu(model, probe, scenes.ATRIUM_CAMERA, size, cfg)
+        r.render()
+        assert _bits_equal(r.downloadAccum(), F.accum) and np.array_equal(r.downloadPixels(), F.frame), kind
+        nodes[kind] = r.stats().num_bvh_nodes
+        r.close()
+    assert 0 < nodes["ploc"] and 0 < nodes["lbvh"] and nodes["ploc"] != nodes["lbvh"]      # two different trees were built
+
+
 _FUZZ = range(int(os.environ.get("FOVPT_FUZZ_FROM", "0")), int(os.environ.get("FOVPT_FUZZ_TO", "10")))      # widen for a sweep
 
 
