@@ -8,9 +8,9 @@
 //   4. Karras 2012 binary radix tree (one thread per internal node)
 //   5. bottom-up AABB refit with per-node arrival counters
 //      (4'/5': default instead of 4/5 -- PLOC, SAH-guided agglomeration along the Morton order)
-//   6. collapse subtrees of <= FOVPT_LEAF_MAX triangles into leaves, collapse the binary tree
-//      top-down into 4-wide 128-byte nodes (largest-area child expanded first), breadth-first
-//      node order; emit 48-byte triangle records in depth-first leaf order
+//   6. cost-optimal collapse into 4-wide 128-byte nodes and leaves of <= FOVPT_LEAF_MAX triangles
+//      (k_dp_collapse bottom-up, k_collapse4 top-down), breadth-first node order; 48-byte triangle
+//      records in depth-first leaf order
 // Results never depend on the tree (see the intersection contract in include/fovpt.h), only
 // speed does.
 #include <cstdio>
@@ -361,8 +361,8 @@ __global__ void k_dp_collapse(int n, const Box* __restrict__ boxes, const uint32
 }
 
 // One level of the top-down 2 -> 4 collapse: every work item is a binary node that becomes a wide node.
-// Its two children are expanded (largest surface area first) until four slots are used or nothing is
-// left to expand; children that stay internal are queued for the next level.
+// Its two children are split over the four slots as k_dp_collapse decided; children that stay internal are
+// queued for the next level.
 __global__ void k_collapse4(int nwork, const Work4* __restrict__ work_in, Work4* __restrict__ work_out, uint32_t* __restrict__ counters,
                             const int* __restrict__ left, const int* __restrict__ right, const uint32_t* __restrict__ size_int,
                             const uint32_t* __restrict__ node_first, const uint32_t* __restrict__ leaf_pos,
