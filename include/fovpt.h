@@ -269,7 +269,7 @@ int fovpt_camera_uvw(const fovpt_float3* eye, const fovpt_float3* lookat, const 
 #define FOVPT_OP_RSQRTD 9   /* (float)(1.0 / (double)sqrtf(a)), maths.h:98 */
 #define FOVPT_OP_UNORM8 10  /* texel channel (uint8)a / 255.0f as the shading kernel computes it */
 int fovpt_debug_math(fovpt_ctx* ctx, int op, const float* a, const float* b, float* out, size_t n);
-/* tests/diagnostics only: device address and size of an internal buffer ("sq_occ", "counters", "hit", ...) */
+/* tests/diagnostics only: device address and size of an internal buffer ("sq_occ", "counters", "hit", "bvh_nodes", ...) */
 int fovpt_debug_buffer(fovpt_ctx* ctx, const char* name, void** ptr, size_t* bytes);
 
 #ifdef __cplusplus
