@@ -15,6 +15,7 @@
 // speed does.
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -315,18 +316,42 @@ __device__ inline float box_area(const Box& b)
 #ifndef FOVPT_COST_LEAF
 #define FOVPT_COST_LEAF 2.7f
 #endif
-struct DpCost {
+struct alignas(16) DpCost {
     float c1, c2, c3;
     uint32_t dec;       // bits 0-1: slots for the left child when x is a wide node; 2: x is a leaf; 3: two slots = (1, 1);
 };                      // bits 4-5: three slots = 0 as for two, 1 (1, 2), 2 (2, 1)
 
-__device__ inline void dp_child(int x, const Box* __restrict__ boxes, const uint32_t* __restrict__ vals, const volatile DpCost* dp,
+__device__ inline void dp_child(int x, const Box* __restrict__ boxes, const uint32_t* __restrict__ vals, const DpCost* dp,
                                 float& a1, float& a2, float& a3)
 {
     if (x < 0) { a1 = a2 = a3 = box_area(boxes[vals[~x]]) * FOVPT_COST_LEAF; }
-    else { a1 = dp[x].c1; a2 = dp[x].c2; a3 = dp[x].c3; }
+    else { const DpCost c = dp[x]; a1 = c.c1; a2 = c.c2; a3 = c.c3; }
 }
 
+__device__ inline void dp_node(int node, const Box* __restrict__ boxes, const uint32_t* __restrict__ vals, const int* __restrict__ left,
+                               const int* __restrict__ right, const uint32_t* __restrict__ size_int, const Box* __restrict__ ibox, DpCost* dp)
+{
+    float l1, l2, l3, r1, r2, r3;
+    dp_child(left[node], boxes, vals, dp, l1, l2, l3);
+    dp_child(right[node], boxes, vals, dp, r1, r2, r3);
+    float s = l1 + r3;
+    uint32_t dec = 1u;
+    if (l2 + r2 < s) { s = l2 + r2; dec = 2u; }
+    if (l3 + r1 < s) { s = l3 + r1; dec = 3u; }
+    const float area = box_area(ibox[node]);
+    float c1 = area + s;
+    if (size_int[node] <= FOVPT_LEAF_MAX && area * FOVPT_COST_LEAF <= c1) { c1 = area * FOVPT_COST_LEAF; dec |= 4u; }
+    float c2 = c1;
+    if (l1 + r1 < c2) { c2 = l1 + r1; dec |= 8u; }
+    float c3 = c2;
+    uint32_t d3 = 0u;
+    if (l1 + r2 < c3) { c3 = l1 + r2; d3 = 1u; }
+    if (l2 + r1 < c3) { c3 = l2 + r1; d3 = 2u; }
+    DpCost out; out.c1 = c1; out.c2 = c2; out.c3 = c3; out.dec = dec | (d3 << 4);
+    dp[node] = out;
+}
+
+// any binary tree: climb from the leaves, the second thread to arrive at a node computes it (fences as in k_refit)
 __global__ void k_dp_collapse(int n, const Box* __restrict__ boxes, const uint32_t* __restrict__ vals, const int* __restrict__ left,
                               const int* __restrict__ right, const int* __restrict__ parent_int, const int* __restrict__ parent_leaf,
                               const uint32_t* __restrict__ size_int, const Box* __restrict__ ibox, DpCost* dp, uint32_t* __restrict__ arrive)
@@ -338,26 +363,18 @@ __global__ void k_dp_collapse(int n, const Box* __restrict__ boxes, const uint32
         __threadfence();
         if (atomicAdd(&arrive[node], 1u) == 0u) return;   // first arrival: the sibling's costs are not there yet
         __threadfence();
-        float l1, l2, l3, r1, r2, r3;
-        dp_child(left[node], boxes, vals, dp, l1, l2, l3);
-        dp_child(right[node], boxes, vals, dp, r1, r2, r3);
-        float s = l1 + r3;
-        uint32_t dec = 1u;
-        if (l2 + r2 < s) { s = l2 + r2; dec = 2u; }
-        if (l3 + r1 < s) { s = l3 + r1; dec = 3u; }
-        const float area = box_area(ibox[node]);
-        float c1 = area + s;
-        if (size_int[node] <= FOVPT_LEAF_MAX && area * FOVPT_COST_LEAF <= c1) { c1 = area * FOVPT_COST_LEAF; dec |= 4u; }
-        float c2 = c1;
-        if (l1 + r1 < c2) { c2 = l1 + r1; dec |= 8u; }
-        float c3 = c2;
-        uint32_t d3 = 0u;
-        if (l1 + r2 < c3) { c3 = l1 + r2; d3 = 1u; }
-        if (l2 + r1 < c3) { c3 = l2 + r1; d3 = 2u; }
-        DpCost out; out.c1 = c1; out.c2 = c2; out.c3 = c3; out.dec = dec | (d3 << 4);
-        dp[node].c1 = out.c1; dp[node].c2 = out.c2; dp[node].c3 = out.c3; dp[node].dec = out.dec;
+        dp_node(node, boxes, vals, left, right, size_int, ibox, dp);
         node = parent_int[node];
     }
+}
+
+// PLOC trees: the nodes of one merge round have all their children in earlier rounds, and their ids are one
+// contiguous range -- one plain launch per round, no fences
+__global__ void k_dp_range(int first, int count, const Box* __restrict__ boxes, const uint32_t* __restrict__ vals, const int* __restrict__ left,
+                           const int* __restrict__ right, const uint32_t* __restrict__ size_int, const Box* __restrict__ ibox, DpCost* dp)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) dp_node(first + i, boxes, vals, left, right, size_int, ibox, dp);
 }
 
 // One level of the top-down 2 -> 4 collapse: every work item is a binary node that becomes a wide node.
@@ -512,6 +529,7 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
     // collapse state
     Work4 *work_a = nullptr, *work_b = nullptr;
     DpCost* dp = nullptr;
+    std::vector<uint32_t> round_end;           // PLOC: internal nodes created up to and including each round
     uint32_t* dp_arrive = nullptr;
     uint32_t* counters = nullptr;
     BvhNode4* nodes = nullptr;
@@ -572,6 +590,7 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
             hipLaunchKernelGGL(k_ploc_init, dim3(gn), dim3(B), 0, st, (int)n, boxes, vals_s, c_node, c_box);
             uint32_t m = n;
             int force = 0, rounds = 0;
+            round_end.clear();
             while (m > 1) {
                 const uint32_t gm = (m + B - 1) / B;
                 hipLaunchKernelGGL(k_ploc_nn, dim3(gm), dim3(B), 0, st, (int)m, force, c_box, nn);
@@ -579,10 +598,12 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
                                    parent_leaf, side_int, side_leaf, ibox, size_int, valid, t_node, t_box);
                 HC(rocprim::exclusive_scan(scan_temp, scan_bytes, valid, pos, 0u, (size_t)m, rocprim::plus<uint32_t>(), st));
                 hipLaunchKernelGGL(k_ploc_compact, dim3(gm), dim3(B), 0, st, (int)m, valid, pos, t_node, t_box, c_node, c_box);
-                uint32_t last_pos = 0, last_valid = 0;
+                uint32_t last_pos = 0, last_valid = 0, made = 0;
+                HC(hipMemcpyAsync(&made, node_counter, 4, hipMemcpyDeviceToHost, st));
                 HC(hipMemcpyAsync(&last_pos, pos + (m - 1), 4, hipMemcpyDeviceToHost, st));
                 HC(hipMemcpyAsync(&last_valid, valid + (m - 1), 4, hipMemcpyDeviceToHost, st));
                 HC(hipStreamSynchronize(st));
+                round_end.push_back(made);
                 const uint32_t m2 = last_pos + last_valid;
                 force = (m2 == m) ? 1 : 0;                     // no mutual pair this round (ties): pair neighbours next round
                 m = m2;
@@ -594,10 +615,21 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
             root = (int)n - 2;                                 // the last merge created the root
         }
         // ---- 2 -> 4 collapse: costs bottom-up, then one launch per level of the wide tree
-        HC(hipMalloc(&dp, sizeof(DpCost) * ni)); HC(hipMalloc(&dp_arrive, 4ull * ni));
-        HC(hipMemsetAsync(dp_arrive, 0, 4ull * ni, st));
-        hipLaunchKernelGGL(k_dp_collapse, dim3(gn), dim3(B), 0, st, (int)n, boxes, vals_s, left, right, parent_int, parent_leaf, size_int, ibox,
-                           dp, dp_arrive);
+        HC(hipMalloc(&dp, sizeof(DpCost) * ni));
+        if (use_ploc) {
+            uint32_t first = 0;
+            for (uint32_t end : round_end) {
+                if (end > first)
+                    hipLaunchKernelGGL(k_dp_range, dim3((end - first + B - 1) / B), dim3(B), 0, st, (int)first, (int)(end - first), boxes, vals_s,
+                                       left, right, size_int, ibox, dp);
+                first = end;
+            }
+        } else {
+            HC(hipMalloc(&dp_arrive, 4ull * ni));
+            HC(hipMemsetAsync(dp_arrive, 0, 4ull * ni, st));
+            hipLaunchKernelGGL(k_dp_collapse, dim3(gn), dim3(B), 0, st, (int)n, boxes, vals_s, left, right, parent_int, parent_leaf, size_int, ibox,
+                               dp, dp_arrive);
+        }
         HC(hipMalloc(&work_a, sizeof(Work4) * ni)); HC(hipMalloc(&work_b, sizeof(Work4) * ni));
         Work4 w0; w0.node = root; w0.out = 0; w0.depth = 0;
         HC(hipMemcpyAsync(work_a, &w0, sizeof(w0), hipMemcpyHostToDevice, st));

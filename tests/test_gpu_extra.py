@@ -48,7 +48,7 @@ def _launch_both(oracle, size, grid, setup, model=None, accumulate=0, prefill=No
         F.accum[...] = prefill
         # upload the same previous-frame accum to the device through a dummy uniform render is not
         # possible; use hipMemcpy via ctypes on the HIP runtime the library already loaded
-        hip = C.CDLL("libamdhip64.so")
+        hip = C.CDLL("libamdhip64.so.7")            # by SONAME: the copy libfovpt.so is bound to, whichever that is
         hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
         assert hip.hipMemcpy(r.launchParams.frame.accum_buffer, prefill.ctypes.data, prefill.nbytes, 1) == 0
     r.launch(*grid)
