@@ -341,11 +341,12 @@ __device__ inline void dp_node(int node, const Box* __restrict__ boxes, const ui
     const float area = box_area(ibox[node]);
     float c1 = area + s;
     if (size_int[node] <= FOVPT_LEAF_MAX && area * FOVPT_COST_LEAF <= c1) { c1 = area * FOVPT_COST_LEAF; dec |= 4u; }
+    // (ties dissolve the node: with degenerate boxes, all costs zero, the wide tree must still get shallower)
     float c2 = c1;
-    if (l1 + r1 < c2) { c2 = l1 + r1; dec |= 8u; }
+    if (l1 + r1 <= c2) { c2 = l1 + r1; dec |= 8u; }
     float c3 = c2;
     uint32_t d3 = 0u;
-    if (l1 + r2 < c3) { c3 = l1 + r2; d3 = 1u; }
+    if (l1 + r2 <= c3) { c3 = l1 + r2; d3 = 1u; }
     if (l2 + r1 < c3) { c3 = l2 + r1; d3 = 2u; }
     DpCost out; out.c1 = c1; out.c2 = c2; out.c3 = c3; out.dec = dec | (d3 << 4);
     dp[node] = out;
@@ -605,7 +606,9 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
                 HC(hipStreamSynchronize(st));
                 round_end.push_back(made);
                 const uint32_t m2 = last_pos + last_valid;
-                force = (m2 == m) ? 1 : 0;                     // no mutual pair this round (ties): pair neighbours next round
+                // (Almost) no mutual pair this round -- coincident geometry: among equal boxes everybody picks the first
+                // candidate of its window and one pair merges per round -- so the next round pairs neighbours.
+                force = ((uint64_t)(m - m2) * 64u < m) ? 1 : 0;
                 m = m2;
                 if (++rounds > 4096) { snprintf(err, errlen, "PLOC did not converge"); goto fail; }
             }

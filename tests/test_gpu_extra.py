@@ -407,6 +407,29 @@ def test_hierarchy_choice_does_not_change_the_frame(oracle, monkeypatch):
     assert 0 < nodes["ploc"] and 0 < nodes["lbvh"] and nodes["ploc"] != nodes["lbvh"]      # two different trees were built
 
 
+@pytest.mark.gpu
+def test_degenerate_geometry_builds_a_shallow_hierarchy(oracle):
+    """Tens of thousands of identical triangles (every box equal, every cost in the collapse tied) next to ordinary
+    geometry: the build must not fail on depth, and the frame is still the oracle's (ties -> lowest primitive id)."""
+    rng = np.random.default_rng(2)
+    n_dup, n_rnd = 40000, 2000
+    one = np.float32([[-0.5, -0.5, 0.0], [0.5, -0.5, 0.0], [0.0, 0.6, 0.0]])
+    tri = np.concatenate([np.broadcast_to(one, (n_dup, 3, 3)),
+                          rng.uniform(-2.0, 2.0, (n_rnd, 1, 3)) + rng.uniform(-0.2, 0.2, (n_rnd, 3, 3))]).astype(np.float32)
+    verts = tri.reshape(-1, 3)
+    idx = np.arange(verts.shape[0], dtype=np.uint32).reshape(-1, 3)
+    model = scenes.Model(meshes=[scenes.TriangleMesh(vertex=verts, index=idx, material=scenes.matte((0.7, 0.6, 0.5), emission=(0.3, 0.3, 0.3)))])
+    cam = dict(eye=(0.0, 0.0, 6.0), lookat=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fovy=40.0)
+    size, cfg = (96, 64), cfg_uniform(1, max_depth=2)
+    r = make_gpu(model, scenes.ambient_probe(32, 16, 1.0), cam, size, cfg)
+    assert 0 < r.stats().bvh_max_depth <= 21
+    r.render()
+    S, F = make_oracle(oracle, model, scenes.ambient_probe(32, 16, 1.0), cam, size)
+    oracle.render(S, F, cfg)
+    assert _bits_equal(r.downloadAccum(), F.accum) and np.array_equal(r.downloadPixels(), F.frame)
+    r.close()
+
+
 _FUZZ = range(int(os.environ.get("FOVPT_FUZZ_FROM", "0")), int(os.environ.get("FOVPT_FUZZ_TO", "10")))      # widen for a sweep
 
 
