@@ -248,6 +248,46 @@ def test_bsdf_table_sanity(oracle):
             assert (t["type"][ok] != 2).all()
 
 
+def test_bsdf_against_an_independent_binary64_restatement(oracle):
+    """BSDFEval / BSDFPdf of the oracle (binary32, the reference's operation order) against tests/disney_f64.py
+    (binary64 numpy, written separately from Disney.cuh's formulae) on the directions BSDFSample draws: every lobe --
+    diffuse, GGX, clearcoat, subsurface, transmission with and without total internal reflection."""
+    import disney_f64 as D
+    rng = np.random.default_rng(17)
+    n = 20000
+    N = rng.normal(size=(n, 3)); N /= np.linalg.norm(N, axis=1, keepdims=True)
+    view = rng.normal(size=(n, 3)); view /= np.linalg.norm(view, axis=1, keepdims=True)
+    view[(N * view).sum(1) < 0] *= -1
+    alb = rng.uniform(0.0, 1.0, (n, 3)); alb[:50] = 0.0                     # black albedo: the Ctint fallback
+    mats = [abi.Material.reference_default(), scenes.matte((0.7, 0.6, 0.5)), scenes.diffuse_only((0.5, 0.5, 0.5))]
+    for kw in (dict(subsurface=0.6, transmission=0.0, metallic=0.2, roughness=0.3, clearcoat=0.8, clearcoatGloss=0.3, specularTint=0.4, specular=0.7),
+               dict(subsurface=0.3, transmission=0.7, metallic=0.0, roughness=0.05, clearcoat=0.0, clearcoatGloss=1.0, specularTint=0.0, specular=1.0),
+               dict(subsurface=0.0, transmission=1.0, metallic=0.6, roughness=0.6, clearcoat=1.0, clearcoatGloss=0.0, specularTint=1.0, specular=0.2)):
+        m = abi.Material.reference_default()
+        m.color.set((0.8, 0.3, 0.1))
+        for k, v in kw.items():
+            setattr(m, k, v)
+        mats.append(m)
+    checked = 0
+    for mat in mats:
+        for eta_i, eta_o in ((1.0, 1.4), (1.4, 1.0)):                        # entering, leaving (TIR happens)
+            t = oracle.bsdf_table(mat, N, view, alb, np.full(n, eta_i), np.full(n, eta_o), np.arange(n) * 7 + 1)
+            L = t["light"].astype(np.float64)
+            ok = (t["pdf"] > 0) & (np.abs(np.linalg.norm(L, axis=1) - 1.0) < 1e-3)
+            Nn, Vv = N.astype(np.float32).astype(np.float64), view.astype(np.float32).astype(np.float64)
+            ev, near_e = D.bsdf_eval(mat, alb.astype(np.float32).astype(np.float64), eta_i, eta_o, Nn, Vv, L)
+            pdf, near_p = D.bsdf_pdf(mat, eta_i, eta_o, Nn, Vv, L)
+            use = ok & ~near_e & ~near_p & np.isfinite(ev).all(1)
+            assert use.sum() > 0.5 * ok.sum() > 0
+            scale = np.maximum(np.abs(ev[use]).max(1), 1e-6)
+            # binary32 rounding of N.H is amplified by ~1/a^2 at the GGX peak of a smooth surface
+            tol = 2e-4 * max(1.0, 0.01 / max(0.001, mat.roughness) ** 2)
+            assert (np.abs(t["eval"][use] - ev[use]).max(1) / scale).max() < tol, (mat.transmission, mat.roughness)
+            assert (np.abs(t["pdf_again"][use] - pdf[use]) / np.maximum(pdf[use], 1e-6)).max() < tol
+            checked += int(use.sum())
+    assert checked > 100000
+
+
 def test_make_color_known_values(oracle):
     c = oracle.make_color(np.float32([[0, 0, 0], [1e6, 1e6, 1e6], [-0.01, -0.01, -0.01]]))
     assert c[0] == 0xFF000000 and c[2] == 0xFF000000
