@@ -228,6 +228,41 @@ def test_probe_sample_properties(oracle):
     assert (uv >= 0).all() and (uv <= 1.0001).all()
 
 
+def test_probe_sampling_against_numpy(oracle):
+    """BuildCDF (Probe.h:29-77) and ProbeSample (Probe.cuh:138-169) restated with numpy in binary64 -- cumulative sums,
+    searchsorted(side="left") for LowerBound, the pdf and direction formulae -- on the oracle's own Random stream
+    (pinned separately by tests/golden/rng_kat.json)."""
+    rng = np.random.default_rng(9)
+    for data in (scenes.sky_probe(64, 32), np.concatenate([rng.uniform(0.0, 4.0, (24, 40, 3)), np.ones((24, 40, 1))], axis=2).astype(np.float32)):
+        h, w = data.shape[:2]
+        probe = oracle.HostProbe(data)
+        lum = 0.3 * data[..., 0].astype(np.float64) + 0.6 * data[..., 1] + 0.1 * data[..., 2]     # maths.h:165
+        row_sum = lum.sum(1)
+        assert np.allclose(probe.pdfx, lum / row_sum[:, None], rtol=2e-5, atol=1e-9)
+        assert np.allclose(probe.cdfx, np.cumsum(lum, 1) / row_sum[:, None], rtol=2e-5, atol=1e-7)
+        assert np.allclose(probe.pdfy, row_sum / row_sum.sum(), rtol=2e-5) and np.allclose(probe.cdfy, np.cumsum(row_sum) / row_sum.sum(), rtol=2e-5)
+        n = 5000
+        d, c, p = oracle.probe_sample(probe, 1234, n)
+        _, f = oracle.random_stream(1234, 2 * n)                     # Sample2D = two Randf() draws per sample (sample.h:254-259)
+        r1, r2 = f[0::2], f[1::2]
+        row = np.minimum(np.searchsorted(probe.cdfy, r1, side="left"), h)
+        inside = row < h
+        rowc = np.minimum(row, h - 1)
+        col = np.array([np.searchsorted(probe.cdfx[rr], x, side="left") for rr, x in zip(rowc, r2)])
+        inside &= col < w
+        colc = np.minimum(col, w - 1)
+        assert inside.mean() > 0.999
+        assert np.array_equal(c[inside], data[rowc, colc, :3][inside])
+        theta, phi = rowc / float(h) * np.pi, colc / float(w) * 2.0 * np.pi          # texel corner, no +0.5
+        want_d = np.stack([-np.sin(theta) * np.cos(phi), np.cos(theta), -np.sin(theta) * np.sin(phi)], 1)
+        assert np.abs(d[inside] - want_d[inside]).max() < 2e-6
+        st = np.sin(theta)
+        with np.errstate(all="ignore"):
+            want_p = np.where(np.float32(st) == 0.0, 0.0, probe.pdfx[rowc, colc].astype(np.float64) * probe.pdfy[rowc] * w * h / (2.0 * np.pi * np.pi * st))
+        ok = inside & (row > 0)                                       # row 0: sin(0) == 0 -> pdf 0 in both
+        assert np.allclose(p[ok], want_p[ok], rtol=1e-4) and (p[inside & (row == 0)] == 0).all()
+
+
 def test_bsdf_table_sanity(oracle):
     rng = np.random.default_rng(5)
     n = 4096
