@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 
 from fovpathtracing_optixcodelatest_amd import abi, scenes
+from common import cfg_foveated
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -226,6 +227,49 @@ def test_probe_sample_properties(oracle):
     assert bright.mean() > 0.3
     uv = oracle.probe_dir_to_uv(d)
     assert (uv >= 0).all() and (uv <= 1.0001).all()
+
+
+def _coverage_numpy(w, h, cx, cy, r_in, r_out):
+    """Which pixels the three launches of render() write (SimplePathtracer.cpp:133-209, deviceProgram.cu:433-440,
+    :545-554), restated with numpy: launch grid -> pixel index in uint32 -> ring test in binary32 -> clamped block fill."""
+    written = np.zeros((h, w), bool)
+    u32 = lambda a: np.asarray(a, np.int64) & 0xffffffff
+    passes = [(4, 4, float(r_out), 1e9, 0, 0, w // 4, h // 4),
+              (2, 2, float(r_in), float(r_out + 2), cx - (r_out + 2), cy - (r_out + 2), r_out + 2, r_out + 2),
+              (1, 1, 0.0, float(r_in + 1), cx - (r_in + 1), cy - (r_in + 1), 2 * (r_in + 1), 2 * (r_in + 1))]
+    for f, fill, lo, hi, offx, offy, gw, gh in passes:
+        ly, lx = np.meshgrid(np.arange(gh, dtype=np.int64), np.arange(gw, dtype=np.int64), indexing="ij")
+        ix, iy = u32(lx * f + u32(offx)), u32(ly * f + u32(offy))
+        dx = ix.astype(np.float32) - np.float32(u32(cx)); dy = iy.astype(np.float32) - np.float32(u32(cy))
+        rng_ = np.sqrt(dx * dx + dy * dy + np.float32(0.0))
+        alive = ~((rng_ < np.float32(lo)) | (rng_ > np.float32(hi)))
+        for i in range(fill):
+            for j in range(fill):
+                px = np.minimum(u32(lx * f + i + u32(offx)), w - 1); py = np.minimum(u32(ly * f + j + u32(offy)), h - 1)
+                written[py[alive], px[alive]] = True
+    return written
+
+
+def test_foveation_coverage_against_numpy(oracle):
+    """With nothing to hit and a constant probe every written pixel holds the probe colour, so the frame shows exactly
+    WHICH pixels the three passes write: compared with a numpy restatement of the launch geometry, gaze on and off the
+    frame centre, at the border and with offsets that wrap below zero."""
+    tri = np.float32([[0, 0, 900], [1, 0, 900], [0, 1, 900]])           # behind the camera
+    model = scenes.Model(meshes=[scenes.TriangleMesh(vertex=tri, index=np.uint32([[0, 1, 2]]), material=scenes.matte((0.5, 0.5, 0.5)))])
+    cam = dict(eye=(0.0, 0.0, 10.0), lookat=(0.0, 0.0, 0.0), up=(0.0, 1.0, 0.0), fovy=40.0)
+    w, h = 256, 144
+    S = oracle.OracleScene(model)
+    hp = oracle.HostProbe(scenes.ambient_probe(32, 16, 0.25))
+    for (cx, cy), (ri, ro) in (((128, 72), (20, 64)), ((60, 100), (17, 41)), ((5, 3), (12, 30)), ((250, 140), (25, 70)), ((128, 72), (74, 241))):
+        F = oracle.OracleFrame(w, h, hp, cam, gaze=(cx, cy))
+        cfg = cfg_foveated(ri, ro, (1, 2, 4))
+        oracle.render(S, F, cfg)
+        want = _coverage_numpy(w, h, cx, cy, ri, ro)
+        got = F.frame != 0
+        assert np.array_equal(got, want), ((cx, cy), (ri, ro), int((got != want).sum()))
+        assert 0.3 < want.mean() <= 1.0
+        assert np.array_equal(F.accum[want][:, :3], np.full((int(want.sum()), 3), 0.25, np.float32))
+        assert (F.accum[~want] == 0).all()
 
 
 def test_probe_sampling_against_numpy(oracle):
