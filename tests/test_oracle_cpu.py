@@ -272,6 +272,54 @@ def test_foveation_coverage_against_numpy(oracle):
         assert (F.accum[~want] == 0).all()
 
 
+def test_camera_rays_and_jitter_against_python(oracle):
+    """Seed = tea<4>(launch index in the FULL frame width, subframe), jitter = two LCG draws with x first, the pixel ->
+    direction map through U, V, W (deviceProgram.cu:411, :479-487): restated with the pure-Python integer RNG of
+    tests/golden/make_golden.py and binary64, and checked through visibility -- which pixels of a 1-spp frame see an
+    emissive rectangle whose silhouette falls between pixel centres."""
+    sys_path_golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(sys_path_golden, "make_golden.py"))
+    G = importlib.util.module_from_spec(spec); spec.loader.exec_module(G)
+    a, b = 2.37, 1.41
+    quad = np.float32([[-a, -b, 0], [a, -b, 0], [a, b, 0], [-a, b, 0]])
+    model = scenes.Model(meshes=[scenes.TriangleMesh(vertex=quad, index=np.uint32([[0, 1, 2], [0, 2, 3]]),
+                                                     material=scenes.matte((0.5, 0.5, 0.5), emission=(5.0, 5.0, 5.0)))])
+    cam = dict(eye=(0.3, -0.2, 10.0), lookat=(0.0, 0.1, 0.0), up=(0.0, 1.0, 0.0), fovy=40.0)
+    w, h = 96, 64
+    S = oracle.OracleScene(model)
+    hp = oracle.HostProbe(scenes.ambient_probe(32, 16, 0.25))
+    from common import cfg_uniform
+    for subframe in (0, 7):
+        F = oracle.OracleFrame(w, h, hp, cam, subframe_index=subframe)
+        oracle.render(S, F, cfg_uniform(1, max_depth=1))
+        saw = ~np.all(F.accum[..., :3] == np.float32(0.25), axis=2)          # anything but the backplate
+        U, V, W = (np.float64(x) for x in oracle.camera_uvw(cam["eye"], cam["lookat"], cam["up"], cam["fovy"], w / h))
+        eye = np.float64(cam["eye"])
+        want = np.zeros((h, w), bool); sure = np.zeros((h, w), bool)
+        for ly in range(h):
+            for lx in range(w):
+                # the shipped FOV_OFF branch renders with subframe_index 0 whatever the caller's counter says (SimplePathtracer.cpp:93)
+                seed = G.tea4(ly * w + lx, 0)
+                jx, jy = (v / float(1 << 24) for v in G.lcg_stream(seed, 2))
+                dx, dy = 2.0 * (lx + jx) / w - 1.0, 2.0 * (ly + jy) / h - 1.0
+                d = dx * U + dy * V + W
+                t = -eye[2] / d[2]
+                x, y = eye[0] + t * d[0], eye[1] + t * d[1]
+                want[ly, lx] = abs(x) < a and abs(y) < b
+                sure[ly, lx] = min(abs(abs(x) - a), abs(abs(y) - b)) > 1e-4
+        assert sure.mean() > 0.99 and 0.1 < want.mean() < 0.8
+        assert np.array_equal(saw[sure], want[sure]), int((saw != want)[sure].sum())
+        # the jitter matters: pixel centres alone (no jitter) give a different silhouette
+        edge = np.zeros((h, w), bool)
+        for ly in range(h):
+            for lx in range(w):
+                d = (2.0 * (lx + 0.5) / w - 1.0) * U + (2.0 * (ly + 0.5) / h - 1.0) * V + W
+                t = -eye[2] / d[2]
+                edge[ly, lx] = abs(eye[0] + t * d[0]) < a and abs(eye[1] + t * d[1]) < b
+        assert (edge != want).sum() > 10
+
+
 def test_probe_sampling_against_numpy(oracle):
     """BuildCDF (Probe.h:29-77) and ProbeSample (Probe.cuh:138-169) restated with numpy in binary64 -- cumulative sums,
     searchsorted(side="left") for LowerBound, the pdf and direction formulae -- on the oracle's own Random stream
