@@ -415,6 +415,24 @@ def test_bsdf_against_an_independent_binary64_restatement(oracle):
     assert checked > 100000
 
 
+def test_tone_mapping_against_numpy(oracle):
+    """accum * 16 -> Reinhard (white 1) -> clamp -> sRGB OETF -> 8 bits (deviceProgram.cu:126-131, :586-597,
+    cuda/helpers.h:35-62) in binary64 numpy; binary32 may land one code away right at a quantisation step."""
+    rng = np.random.default_rng(23)
+    rgb = np.concatenate([rng.uniform(0.0, 0.2, (20000, 3)), rng.uniform(0.0, 5.0, (5000, 3)), 10.0 ** rng.uniform(-6, 1, (5000, 3)),
+                          np.float64([[0, 0, 0], [1e-5, 2e-5, 3e-5], [1e3, 1e3, 1e3], [-1, -2, -3]])]).astype(np.float32)
+    got = oracle.make_color(rgb)
+    c = rgb.astype(np.float64) * 16.0
+    lum = 0.2126 * c[:, 0] + 0.7152 * c[:, 1] + 0.0722 * c[:, 2]
+    t = np.clip(c / (1.0 + lum)[:, None], 0.0, 1.0)
+    srgb = np.where(t < 0.0031308, 12.92 * t, 1.055 * t ** (1.0 / 2.4) - 0.055)
+    q = np.minimum((np.clip(srgb, 0.0, 1.0) * 256.0).astype(np.int64), 255)
+    want = q[:, 0] | (q[:, 1] << 8) | (q[:, 2] << 16) | (255 << 24)
+    ch = lambda v, k: ((v >> (8 * k)) & 255).astype(np.int64)
+    diff = np.stack([np.abs(ch(got.astype(np.int64), k) - ch(want, k)) for k in range(3)], 1)
+    assert (got >> 24 == 255).all() and diff.max() <= 1 and (diff == 0).all(1).mean() > 0.995
+
+
 def test_make_color_known_values(oracle):
     c = oracle.make_color(np.float32([[0, 0, 0], [1e6, 1e6, 1e6], [-0.01, -0.01, -0.01]]))
     assert c[0] == 0xFF000000 and c[2] == 0xFF000000
