@@ -113,3 +113,93 @@ def bsdf_eval(mat, albedo, eta_i, eta_o, N, V, L):
             + (mat.clearcoat * gr * fc * dr)[:, None]
         brdf = np.where((ndl <= 0)[:, None], below, above)
     return _lerp(brdf, bsdf, mat.transmission), near
+
+
+# ---- BSDFSample (Disney.cuh:197-315) as scalar Python: the order of the random draws and the branch structure -------
+M32 = 0xFFFFFFFF
+TWO_PI = 2.0 * float(PI)
+
+
+class PyRandom:
+    """class Random (maths.h:170-227) on Python integers."""
+
+    def __init__(self, seed):
+        self.s1 = (315645664 + seed) & M32
+        self.s2 = self.s1 ^ 0x13AB45FE
+
+    def rand(self):
+        rot5 = ((self.s1 << 5) | (self.s1 >> 27)) & M32
+        self.s1 = ((self.s2 ^ rot5) ^ ((self.s1 * self.s2) & M32)) & M32
+        rot12 = ((self.s2 << 12) | (self.s2 >> 20)) & M32
+        self.s2 = (self.s1 ^ rot12) & M32
+        return self.s1
+
+    def randf(self):
+        f = float(np.float32(self.rand()) * (np.float32(1.0) / np.float32(0xFFFFFFFF)))
+        return min(max(f, 0.0), float(np.float32(0.999999)))
+
+
+def basis_from_vector(w):                                # maths.h:94-108
+    if abs(w[0]) > abs(w[1]):
+        il = 1.0 / np.sqrt(w[0] * w[0] + w[2] * w[2])
+        u = np.float64([-w[2] * il, 0.0, w[0] * il])
+    else:
+        il = 1.0 / np.sqrt(w[1] * w[1] + w[2] * w[2])
+        u = np.float64([0.0, w[2] * il, -w[1] * il])
+    return u, np.cross(w, u)
+
+
+def _fr1(vdn, eta_i, eta_t):
+    F, _ = fresnel(np.float64([vdn]), eta_i, eta_t)
+    return float(F[0])
+
+
+def bsdf_sample(mat, eta_i, eta_o, N, view, rnd):
+    """-> (light or None, type 0 reflected / 1 transmitted / 2 specular, early_pdf or None, margin): `margin` is the
+    smallest distance of a random draw or a sign test from the threshold that decided a branch."""
+    U, V = basis_from_vector(N)
+    margin = 1.0
+
+    def draw_below(limit):
+        nonlocal margin
+        x = rnd.randf()
+        margin = min(margin, abs(x - limit))
+        return x < limit
+
+    def ggx_reflect(r1, r2):
+        nonlocal margin
+        a = max(0.001, mat.roughness)
+        phi = r1 * TWO_PI
+        ct = np.sqrt((1.0 - r2) / (1.0 + (a * a - 1.0) * r2))
+        st = np.sqrt(max(0.0, 1.0 - ct * ct))
+        half = U * (st * np.cos(phi)) + V * (st * np.sin(phi)) + N * ct
+        hv = float(np.dot(half, view))
+        margin = min(margin, abs(hv))
+        if hv <= 0.0:
+            half = -half
+        return 2.0 * float(np.dot(view, half)) * half - view
+
+    if draw_below(mat.transmission):
+        F = _fr1(float(np.dot(N, view)), eta_i, eta_o)
+        if draw_below(F):
+            r1, r2 = rnd.randf(), rnd.randf()
+            return ggx_reflect(r1, r2), 0, None, margin
+        eta = eta_i / eta_o
+        ci = float(np.dot(N, view))
+        s2t = eta * eta * max(0.0, 1.0 - ci * ci)
+        margin = min(margin, abs(s2t - 1.0))
+        if s2t >= 1.0:
+            return None, 2, 0.0, margin
+        ct = np.sqrt(1.0 - s2t)
+        return eta * -view + (eta * ci - ct) * N, 2, (1.0 - F) * mat.transmission, margin
+    r1, r2 = rnd.randf(), rnd.randf()
+    if draw_below(0.5):
+        if draw_below(mat.subsurface):
+            z = rnd.randf()
+            w = np.sqrt(1.0 - z * z)
+            phi = TWO_PI * rnd.randf()
+            return U * (np.cos(phi) * w) + V * (np.sin(phi) * w) - N * z, 1, None, margin
+        r, th = np.sqrt(r1), TWO_PI * r2
+        x, y = r * np.cos(th), r * np.sin(th)
+        return U * x + V * y + N * np.sqrt(max(0.0, 1.0 - x * x - y * y)), 0, None, margin
+    return ggx_reflect(r1, r2), 0, None, margin

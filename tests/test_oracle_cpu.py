@@ -415,6 +415,48 @@ def test_bsdf_against_an_independent_binary64_restatement(oracle):
     assert checked > 100000
 
 
+def test_bsdf_sample_draw_order_against_python(oracle):
+    """BSDFSample (Disney.cuh:197-315): which lobe is sampled, in which order the random numbers are consumed and where
+    the stream stands afterwards -- against the scalar Python statement in tests/disney_f64.py, which runs its own
+    integer `Random`.  Samples decided within 1e-5 of a branch threshold are left out."""
+    import disney_f64 as D
+    rng = np.random.default_rng(31)
+    n = 3000
+    N = rng.normal(size=(n, 3)); N /= np.linalg.norm(N, axis=1, keepdims=True)
+    view = rng.normal(size=(n, 3)); view /= np.linalg.norm(view, axis=1, keepdims=True)
+    view[(N * view).sum(1) < 0] *= -1
+    N32, V32 = N.astype(np.float32), view.astype(np.float32)
+    alb = np.full((n, 3), 0.5)
+    mats = [abi.Material.reference_default(), scenes.matte((0.7, 0.6, 0.5))]
+    for kw in (dict(subsurface=0.6, transmission=0.0, roughness=0.3), dict(subsurface=0.3, transmission=0.7, roughness=0.1),
+               dict(subsurface=0.0, transmission=1.0, roughness=0.6)):
+        m = abi.Material.reference_default()
+        for k, v in kw.items():
+            setattr(m, k, v)
+        mats.append(m)
+    seen_types, compared = set(), 0
+    for mat in mats:
+        for eta_i, eta_o in ((1.0, 1.4), (1.4, 1.0)):
+            seeds = np.arange(n) * 13 + 5
+            t = oracle.bsdf_table(mat, N32, V32, alb, np.full(n, eta_i), np.full(n, eta_o), seeds)
+            for i in range(n):
+                r = D.PyRandom(int(seeds[i]))
+                light, typ, early, margin = D.bsdf_sample(mat, eta_i, eta_o, N32[i].astype(np.float64), V32[i].astype(np.float64), r)
+                if margin < 1e-5:
+                    continue
+                assert (int(t["rng_after"][i, 0]), int(t["rng_after"][i, 1])) == (r.s1, r.s2), (i, typ)
+                if light is None:
+                    assert t["pdf"][i] == 0.0
+                    continue
+                assert np.abs(t["light"][i] - light).max() < 5e-5, (i, typ, margin)
+                if early is not None:                                    # the specular branch returns its own pdf
+                    assert t["type"][i] == 2 and abs(t["pdf"][i] - early) <= 2e-5 * max(early, 1e-3)
+                elif t["pdf"][i] > 0:
+                    assert t["type"][i] == typ
+                seen_types.add(typ); compared += 1
+    assert seen_types == {0, 1, 2} and compared > 25000
+
+
 def test_tone_mapping_against_numpy(oracle):
     """accum * 16 -> Reinhard (white 1) -> clamp -> sRGB OETF -> 8 bits (deviceProgram.cu:126-131, :586-597,
     cuda/helpers.h:35-62) in binary64 numpy; binary32 may land one code away right at a quantisation step."""
