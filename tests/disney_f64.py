@@ -109,8 +109,9 @@ def bsdf_eval(mat, albedo, eta_i, eta_o, N, V, L):
         fc = _lerp(0.04, 1.0, FH)
         with np.errstate(all="ignore"):
             gr = smith_ggx(ndl, 0.25) * smith_ggx(ndv, 0.25)
-        above = (INV_PI * fd)[:, None] * albedo * (1.0 - mat.metallic) * (1.0 - mat.subsurface) + (gs * ds)[:, None] * fs \
-            + (mat.clearcoat * gr * fc * dr)[:, None]
+        with np.errstate(all="ignore"):
+            above = (INV_PI * fd)[:, None] * albedo * (1.0 - mat.metallic) * (1.0 - mat.subsurface) + (gs * ds)[:, None] * fs \
+                + (mat.clearcoat * gr * fc * dr)[:, None]
         brdf = np.where((ndl <= 0)[:, None], below, above)
     return _lerp(brdf, bsdf, mat.transmission), near
 

@@ -1,0 +1,169 @@
+"""An end-to-end SECOND statement of the path -- scalar Python, binary64, brute-force intersection -- written from
+PT_sv5_/deviceProgram.cu (raygen :392-617, closest hit :619-732, miss :253-282, SampleLights :303-344), Probe.cuh and,
+through tests/disney_f64.py, Disney.cuh.  It shares no code with oracle/ and is far too slow for anything but the
+tiny frames of tests/test_oracle_cpu.py::test_whole_frames_against_the_python_path_tracer: a checker of the checker."""
+import numpy as np
+
+import disney_f64 as D
+
+TMIN, TMAX = 0.01, 1e16
+M32 = 0xFFFFFFFF
+
+
+def tea4(v0, v1):                                                        # cuda/random.h:34-47
+    s0 = 0
+    for _ in range(4):
+        s0 = (s0 + 0x9E3779B9) & M32
+        v0 = (v0 + ((((v1 << 4) & M32) + 0xA341316C) & M32 ^ ((v1 + s0) & M32) ^ (((v1 >> 5) + 0xC8013EA4) & M32))) & M32
+        v1 = (v1 + ((((v0 << 4) & M32) + 0xAD90777D) & M32 ^ ((v0 + s0) & M32) ^ (((v0 >> 5) + 0x7E95761E) & M32))) & M32
+    return v0
+
+
+class Scene:
+    def __init__(self, model):
+        self.v0, self.e1, self.e2, self.mat = [], [], [], []
+        for mesh in model.meshes:
+            v = mesh.vertex.astype(np.float64)
+            for a, b, c in mesh.index:
+                self.v0.append(v[a]); self.e1.append(v[b] - v[a]); self.e2.append(v[c] - v[a]); self.mat.append(mesh.material)
+        self.v0, self.e1, self.e2 = np.array(self.v0), np.array(self.e1), np.array(self.e2)
+
+    def candidates(self, o, d):
+        """Moeller-Trumbore against every triangle -> (t, det, valid) arrays; a candidate has tmin < t < tmax."""
+        p = np.cross(d, self.e2)
+        det = (self.e1 * p).sum(1)
+        with np.errstate(all="ignore"):
+            inv = 1.0 / det
+            s = o - self.v0
+            u = (s * p).sum(1) * inv
+            q = np.cross(s, self.e1)
+            v = (q * d).sum(1) * inv
+            t = (self.e2 * q).sum(1) * inv
+            ok = (det != 0) & (u >= 0) & (v >= 0) & (u + v <= 1) & (t > TMIN) & (t < TMAX)
+        return t, det, ok
+
+    def closest(self, o, d):
+        t, _, ok = self.candidates(o, d)
+        if not ok.any():
+            return None
+        tt = np.where(ok, t, np.inf)
+        k = int(np.argmin(tt))                                            # argmin takes the lowest index among ties
+        return k, float(tt[k])
+
+    def occluded(self, o, d):                                            # any front-facing candidate (back faces culled, :241)
+        _, det, ok = self.candidates(o, d)
+        return bool((ok & (det > 0)).any())
+
+
+class ProbeF64:
+    def __init__(self, host_probe):
+        self.data = host_probe.data.astype(np.float64)
+        self.h, self.w = self.data.shape[:2]
+        self.pdfx, self.cdfx, self.pdfy, self.cdfy = host_probe.pdfx, host_probe.cdfx, host_probe.pdfy, host_probe.cdfy
+
+    def eval_dir(self, d):                                               # ProbeEval(ProbeDirToUV(d)), Probe.cuh:38-46,61-67
+        theta = np.arccos(min(1.0, max(-1.0, d[1])))
+        phi = 0.0 if (d[0] == 0.0 and d[2] == 0.0) else np.arctan2(d[2], d[0])
+        u, v = (np.pi + phi) / (2.0 * np.pi), theta / np.pi
+        px = min(max(int(u * self.w), 0), self.w - 1); py = min(max(int(v * self.h), 0), self.h - 1)
+        return self.data[py, px, :3]
+
+    def sample(self, rnd):                                               # ProbeSample, Probe.cuh:138-169
+        r1, r2 = rnd.randf(), rnd.randf()
+        row = int(np.searchsorted(self.cdfy, np.float32(r1), side="left"))
+        row_c = min(row, self.h - 1)
+        col = int(np.searchsorted(self.cdfx[row_c], np.float32(r2), side="left"))
+        col_c = min(col, self.w - 1)
+        color = self.data[row_c, col_c, :3]
+        pdf = float(self.pdfx[row_c, col_c]) * float(self.pdfy[row_c])
+        theta, phi = row / float(self.h) * np.pi, col / float(self.w) * 2.0 * np.pi
+        st = np.sin(theta)
+        pdf = 0.0 if np.float32(st) == 0.0 else pdf * self.w * self.h / (2.0 * np.pi * np.pi * st)
+        edge = row >= self.h or col >= self.w
+        return np.float64([-st * np.cos(phi), np.cos(theta), -st * np.sin(phi)]), color, pdf, edge
+
+
+def render_uniform(model, probe, cam_uvw, eye, w, h, spp, max_depth):
+    """FOV_OFF frame (SimplePathtracer.cpp:85-131): factor 1, offset 0, every launch index alive, subframe 0.
+    -> accum (h, w, 3) binary64, doubtful (h, w) bool: a branch was decided within rounding of its threshold."""
+    sc, pr = Scene(model), ProbeF64(probe)
+    U, V, W = (np.float64(x) for x in cam_uvw)
+    eye = np.float64(eye)
+    accum = np.zeros((h, w, 3)); doubtful = np.zeros((h, w), bool)
+    for ly in range(h):
+        for lx in range(w):
+            seed = tea4(ly * w + lx, 0)
+            result, alpha_sum, backplate = np.zeros(3), np.zeros(3), np.zeros(3)
+            doubt = False
+            for _ in range(spp):
+                rnd = D.PyRandom(seed)                                    # seeded before the jitter draws (:466)
+                seed = (1664525 * seed + 1013904223) & M32; jx = (seed & 0xFFFFFF) / float(1 << 24)
+                seed = (1664525 * seed + 1013904223) & M32; jy = (seed & 0xFFFFFF) / float(1 << 24)
+                dx, dy = 2.0 * (lx + jx) / w - 1.0, 2.0 * (ly + jy) / h - 1.0
+                d = dx * U + dy * V + W
+                d /= np.linalg.norm(d)
+                o = eye.copy()
+                backplate = pr.eval_dir(d)
+                thr, ray_eta, done, secondary, depth = np.ones(3), 1.0, False, False, 0
+                direct, indirect, alpha = np.zeros(3), np.zeros(3), np.zeros(3)
+                while True:
+                    radiance = np.zeros(3)
+                    hit = sc.closest(o, d)
+                    if hit is None:
+                        done = True
+                    else:
+                        k, t = hit
+                        mat = sc.mat[k]
+                        n0 = np.cross(sc.e1[k], sc.e2[k]); n0 /= np.linalg.norm(n0)
+                        facing = float(np.dot(-d, n0))
+                        doubt |= abs(facing) < 1e-6
+                        N = n0 if facing >= 0.0 else -n0
+                        P = o + t * d
+                        albedo = np.float64([mat.color.x, mat.color.y, mat.color.z])
+                        out_eta = (mat.eta if mat.eta != 0.0 else 2.0 / (1.0 - np.sqrt(0.08 * mat.specular)) - 1.0) if ray_eta == 1.0 else 1.0
+                        wo = -d
+                        # SampleLights
+                        wi, sky, sky_pdf, edge = pr.sample(rnd)
+                        doubt |= edge
+                        if not sc.occluded(P, wi):
+                            pdf, near_p = D.bsdf_pdf(mat, ray_eta, out_eta, N[None], wo[None], wi[None])
+                            f, near_e = D.bsdf_eval(mat, albedo[None], ray_eta, out_eta, N[None], wo[None], wi[None])
+                            doubt |= bool(near_p[0] or near_e[0])
+                            if pdf[0] > 0.0:
+                                wgt = 0.5 * sky_pdf / (0.5 * pdf[0] + 0.5 * sky_pdf)
+                                if wgt > 0.0:
+                                    radiance = radiance + thr * (wgt * sky * f[0] * abs(float(np.dot(wi, N))) / sky_pdf)
+                        alpha = np.ones(3)
+                        if not secondary:
+                            radiance = radiance + np.float64([mat.emission.x, mat.emission.y, mat.emission.z])
+                        light, typ, early, margin = D.bsdf_sample(mat, ray_eta, out_eta, N, wo, rnd)
+                        doubt |= margin < 1e-5
+                        if light is None:
+                            pdf_s = 0.0
+                        elif early is not None:
+                            pdf_s = early
+                        else:
+                            pp, near_p = D.bsdf_pdf(mat, ray_eta, out_eta, N[None], wo[None], light[None])
+                            pdf_s = float(pp[0]); doubt |= bool(near_p[0])
+                        if pdf_s <= 0.0:
+                            done = True
+                        else:
+                            f, near_e = D.bsdf_eval(mat, albedo[None], ray_eta, out_eta, N[None], wo[None], light[None])
+                            doubt |= bool(near_e[0])
+                            if float(np.dot(light, N)) <= 0.0:
+                                ray_eta = out_eta
+                            thr = thr * f[0] * abs(float(np.dot(N, light))) / pdf_s
+                            o, d, secondary = P, light, True
+                    if done or depth >= max_depth:                       # before the radiance is added (:515)
+                        break
+                    if depth == 0:
+                        direct = direct + radiance
+                    else:
+                        indirect = indirect + radiance
+                    depth += 1
+                result = result + direct + indirect
+                alpha_sum = alpha_sum + alpha
+            a = alpha_sum / spp
+            accum[ly, lx] = (backplate * spp * (1.0 - a) + result) / spp     # backplate of the last sample (:558-560)
+            doubtful[ly, lx] = doubt
+    return accum, doubtful
