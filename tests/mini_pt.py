@@ -86,20 +86,43 @@ class ProbeF64:
 def render_uniform(model, probe, cam_uvw, eye, w, h, spp, max_depth):
     """FOV_OFF frame (SimplePathtracer.cpp:85-131): factor 1, offset 0, every launch index alive, subframe 0.
     -> accum (h, w, 3) binary64, doubtful (h, w) bool: a branch was decided within rounding of its threshold."""
+    accum = np.zeros((h, w, 3)); doubtful = np.zeros((h, w), bool)
+    launch(model, probe, cam_uvw, eye, w, h, accum, doubtful, (w, h), 1, 1, (0, 0), (0, 0), 0.0, 1e9, spp, 0, max_depth)
+    return accum, doubtful
+
+
+def render_foveated(model, probe, cam_uvw, eye, w, h, gaze, r_inner, r_outer, spp_pmf, subframe, max_depth):
+    """FOV_ON frame (SimplePathtracer.cpp:133-209): periphery, middle ring, fovea, later launches overwrite earlier ones;
+    only the periphery launch uses the running subframe index.  Pixels no launch writes stay NaN."""
+    accum = np.full((h, w, 3), np.nan); doubtful = np.zeros((h, w), bool)
+    cx, cy = gaze
+    launch(model, probe, cam_uvw, eye, w, h, accum, doubtful, (w // 4, h // 4), 4, 4, (0, 0), gaze, float(r_outer), 1e9, spp_pmf[0], subframe, max_depth)
+    launch(model, probe, cam_uvw, eye, w, h, accum, doubtful, (r_outer + 2, r_outer + 2), 2, 2, (cx - (r_outer + 2), cy - (r_outer + 2)), gaze,
+           float(r_inner), float(r_outer + 2), spp_pmf[1], 0, max_depth)
+    launch(model, probe, cam_uvw, eye, w, h, accum, doubtful, (2 * (r_inner + 1), 2 * (r_inner + 1)), 1, 1, (cx - (r_inner + 1), cy - (r_inner + 1)), gaze,
+           0.0, float(r_inner + 1), spp_pmf[2], 0, max_depth)
+    return accum, doubtful
+
+
+def launch(model, probe, cam_uvw, eye, w, h, accum, doubtful, grid, factor, fill, offset, gaze, r_in, r_out, spp, subframe, max_depth):
+    """One optixLaunch of __raygen__renderFrame over `grid` launch indices, writing its block fills into accum."""
     sc, pr = Scene(model), ProbeF64(probe)
     U, V, W = (np.float64(x) for x in cam_uvw)
     eye = np.float64(eye)
-    accum = np.zeros((h, w, 3)); doubtful = np.zeros((h, w), bool)
-    for ly in range(h):
-        for lx in range(w):
-            seed = tea4(ly * w + lx, 0)
+    for ly in range(grid[1]):
+        for lx in range(grid[0]):
+            ix, iy = (lx * factor + offset[0]) & M32, (ly * factor + offset[1]) & M32        # uint arithmetic (:433)
+            rng_ = np.sqrt(np.float32(np.float32(ix) - np.float32(gaze[0] & M32)) ** 2 + np.float32(np.float32(iy) - np.float32(gaze[1] & M32)) ** 2)
+            if rng_ < np.float32(r_in) or rng_ > np.float32(r_out):
+                continue
+            seed = tea4(ly * w + lx, subframe)                                                # launch index, FULL frame width (:411)
             result, alpha_sum, backplate = np.zeros(3), np.zeros(3), np.zeros(3)
             doubt = False
             for _ in range(spp):
                 rnd = D.PyRandom(seed)                                    # seeded before the jitter draws (:466)
                 seed = (1664525 * seed + 1013904223) & M32; jx = (seed & 0xFFFFFF) / float(1 << 24)
                 seed = (1664525 * seed + 1013904223) & M32; jy = (seed & 0xFFFFFF) / float(1 << 24)
-                dx, dy = 2.0 * (lx + jx) / w - 1.0, 2.0 * (ly + jy) / h - 1.0
+                dx, dy = 2.0 * (float(np.float32(ix)) + jx) / w - 1.0, 2.0 * (float(np.float32(iy)) + jy) / h - 1.0
                 d = dx * U + dy * V + W
                 d /= np.linalg.norm(d)
                 o = eye.copy()
@@ -164,6 +187,9 @@ def render_uniform(model, probe, cam_uvw, eye, w, h, spp, max_depth):
                 result = result + direct + indirect
                 alpha_sum = alpha_sum + alpha
             a = alpha_sum / spp
-            accum[ly, lx] = (backplate * spp * (1.0 - a) + result) / spp     # backplate of the last sample (:558-560)
-            doubtful[ly, lx] = doubt
-    return accum, doubtful
+            colour = (backplate * spp * (1.0 - a) + result) / spp             # backplate of the last sample (:558-560)
+            for i in range(fill):
+                for j in range(fill):
+                    px = min((lx * factor + i + offset[0]) & M32, w - 1); py = min((ly * factor + j + offset[1]) & M32, h - 1)   # clamp (:554)
+                    accum[py, px] = colour
+                    doubtful[py, px] = doubt

@@ -492,6 +492,26 @@ def test_whole_frames_against_the_python_path_tracer(oracle):
         assert np.median(err) < 1e-5 and want.max() > 0.1
 
 
+def test_a_foveated_frame_against_the_python_path_tracer(oracle):
+    """The three launches of render() -- periphery blocks, middle ring, fovea, each with its sample count, seeds from the
+    launch index, subframe 0 for the inner two -- through tests/mini_pt.py: radiance AND layout of a whole foveated frame."""
+    import mini_pt
+    model, cam = scenes.cornell_box(), scenes.CORNELL_CAMERA
+    w, h, gaze, ri, ro = 48, 32, (27, 14), 5, 11
+    S = oracle.OracleScene(model)
+    hp = oracle.HostProbe(scenes.sky_probe(16, 8, seed=2))
+    for subframe in (0, 3):
+        F = oracle.OracleFrame(w, h, hp, cam, gaze=gaze, subframe_index=subframe)
+        oracle.render(S, F, cfg_foveated(ri, ro, (1, 2, 3), max_depth=3))
+        uvw = oracle.camera_uvw(cam["eye"], cam["lookat"], cam["up"], cam["fovy"], w / h)
+        want, doubtful = mini_pt.render_foveated(model, hp, uvw, cam["eye"], w, h, gaze, ri, ro, (1, 2, 3), subframe, 3)
+        written = ~np.isnan(want[..., 0])
+        assert 0.5 < written.mean() < 1.0 and np.array_equal(written, F.accum[..., 3] == 1.0)     # same pixels written, same holes left
+        got = F.accum[..., :3].astype(np.float64)[written]
+        err = np.abs(got - want[written]).max(1) / np.maximum(np.abs(want[written]).max(1), 0.05)
+        assert (err < 1e-3).mean() > 0.97 and err[~doubtful[written]].max() < 1e-3 and np.median(err) < 1e-5, (float((err < 1e-3).mean()), float(np.median(err)))
+
+
 def test_tone_mapping_against_numpy(oracle):
     """accum * 16 -> Reinhard (white 1) -> clamp -> sRGB OETF -> 8 bits (deviceProgram.cu:126-131, :586-597,
     cuda/helpers.h:35-62) in binary64 numpy; binary32 may land one code away right at a quantisation step."""
