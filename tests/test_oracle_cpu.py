@@ -512,6 +512,39 @@ def test_a_foveated_frame_against_the_python_path_tracer(oracle):
         assert (err < 1e-3).mean() > 0.97 and err[~doubtful[written]].max() < 1e-3 and np.median(err) < 1e-5, (float((err < 1e-3).mean()), float(np.median(err)))
 
 
+def test_accumulate_mode_formula_against_numpy(oracle):
+    """PT_sv4_vmv2/deviceProgram.cu:545-553: with subframe_index > 0 and redraw == 0 a launch writes
+    lerp(previous, clamp(new, 0, 10), 1 / (subframe_index + 1)); otherwise the new value.  `new` is what the same
+    launch writes with accumulation off."""
+    model, cam = scenes.cornell_box(), scenes.CORNELL_CAMERA
+    w, h = 40, 24
+    S = oracle.OracleScene(model)
+    hp = oracle.HostProbe(scenes.sky_probe(16, 8, seed=4))
+    prev = np.random.default_rng(8).uniform(0.0, 12.0, (h, w, 4)).astype(np.float32)
+
+    def run(accumulate, subframe, redraw):
+        F = oracle.OracleFrame(w, h, hp, cam, subframe_index=subframe)
+        f = F.lp.frame
+        f.factor.x, f.factor.y, f.factor.z, f.fillSize = 2, 2, 1, 2
+        f.r_inner, f.r_outer, f.redraw = 0.0, 1e9, redraw
+        F.lp.samples_per_launch = 2
+        F.accum[...] = prev
+        oracle.launch(S, F, w // 2, h // 2, max_depth=3, accumulate=accumulate)
+        return F.accum.copy()
+
+    for subframe, redraw in ((5, 0), (1, 0), (0, 0), (5, 1)):
+        new = run(0, subframe, redraw)[..., :3]
+        got = run(1, subframe, redraw)[..., :3]
+        if subframe > 0 and not redraw:
+            a = np.float32(1.0) / np.float32(subframe + 1)
+            c = np.clip(new, np.float32(0.0), np.float32(10.0))
+            want = prev[..., :3] + (c - prev[..., :3]) * a                   # lerp(a, b, t) = a + t * (b - a), binary32
+            assert np.abs(got - want).max() <= 2e-6 * max(1.0, float(np.abs(want).max()))
+            assert not np.array_equal(got, new)
+        else:
+            assert np.array_equal(got, new)
+
+
 def test_tone_mapping_against_numpy(oracle):
     """accum * 16 -> Reinhard (white 1) -> clamp -> sRGB OETF -> 8 bits (deviceProgram.cu:126-131, :586-597,
     cuda/helpers.h:35-62) in binary64 numpy; binary32 may land one code away right at a quantisation step."""
