@@ -137,6 +137,11 @@ def launch(model, probe, cam_uvw, eye, w, h, accum, doubtful, grid, factor, fill
                     else:
                         k, t = hit
                         mat = sc.mat[k]
+                        catcher = (mat.flags & 1) != 0                    # MATERIAL_FLAG_SHADOW_CATCHER (Material.h:9)
+                    if hit is not None and catcher and secondary:
+                        o = o + hit[1] * d                                # pass through, the bounce does not count (:646-651)
+                        depth -= 1
+                    elif hit is not None:
                         n0 = np.cross(sc.e1[k], sc.e2[k]); n0 /= np.linalg.norm(n0)
                         facing = float(np.dot(-d, n0))
                         doubt |= abs(facing) < 1e-6
@@ -148,15 +153,20 @@ def launch(model, probe, cam_uvw, eye, w, h, accum, doubtful, grid, factor, fill
                         # SampleLights
                         wi, sky, sky_pdf, edge = pr.sample(rnd)
                         doubt |= edge
-                        if not sc.occluded(P, wi):
+                        val = np.zeros(3)
+                        if sc.occluded(P, wi) == catcher:                 # SampleLights counts visible, SampleShadow occluded samples
                             pdf, near_p = D.bsdf_pdf(mat, ray_eta, out_eta, N[None], wo[None], wi[None])
                             f, near_e = D.bsdf_eval(mat, albedo[None], ray_eta, out_eta, N[None], wo[None], wi[None])
                             doubt |= bool(near_p[0] or near_e[0])
                             if pdf[0] > 0.0:
                                 wgt = 0.5 * sky_pdf / (0.5 * pdf[0] + 0.5 * sky_pdf)
                                 if wgt > 0.0:
-                                    radiance = radiance + thr * (wgt * sky * f[0] * abs(float(np.dot(wi, N))) / sky_pdf)
-                        alpha = np.ones(3)
+                                    val = wgt * sky * f[0] * abs(float(np.dot(wi, N))) / sky_pdf
+                        if not catcher:
+                            radiance = radiance + thr * val
+                            alpha = np.ones(3)
+                        else:
+                            alpha = alpha + thr * val                     # (:691-694)
                         if not secondary:
                             radiance = radiance + np.float64([mat.emission.x, mat.emission.y, mat.emission.z])
                         light, typ, early, margin = D.bsdf_sample(mat, ray_eta, out_eta, N, wo, rnd)

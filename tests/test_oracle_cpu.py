@@ -492,6 +492,28 @@ def test_whole_frames_against_the_python_path_tracer(oracle):
         assert np.median(err) < 1e-5 and want.max() > 0.1
 
 
+def test_shadow_catcher_against_the_python_path_tracer(oracle):
+    """MATERIAL_FLAG_SHADOW_CATCHER (deviceProgram.cu:646-651, :691-694, SampleShadow :346-385): a primary hit turns occluded
+    probe samples into alpha and the backplate shows through 1 - alpha; secondary rays pass through without using up depth."""
+    import mini_pt
+    from common import cfg_uniform
+    model, cam = scenes.cornell_box(), scenes.CORNELL_CAMERA
+    model.meshes[0].material.flags = abi.MATERIAL_FLAG_SHADOW_CATCHER      # floor + ceiling + back wall
+    w, h, spp, depth = 20, 20, 2, 3
+    S = oracle.OracleScene(model)
+    hp = oracle.HostProbe(scenes.sky_probe(16, 8, seed=6))
+    F = oracle.OracleFrame(w, h, hp, cam)
+    oracle.render(S, F, cfg_uniform(spp, max_depth=depth))
+    uvw = oracle.camera_uvw(cam["eye"], cam["lookat"], cam["up"], cam["fovy"], w / h)
+    want, doubtful = mini_pt.render_uniform(model, hp, uvw, cam["eye"], w, h, spp, depth)
+    plain = scenes.cornell_box()
+    want_plain, _ = mini_pt.render_uniform(plain, hp, uvw, cam["eye"], w, h, spp, depth)
+    got = F.accum[..., :3].astype(np.float64)
+    err = np.abs(got - want).max(2) / np.maximum(np.abs(want).max(2), 0.05)
+    assert (err < 1e-3).mean() > 0.97 and err[~doubtful].max() < 1e-3 and np.median(err) < 1e-5, (float((err < 1e-3).mean()), float(np.median(err)))
+    assert np.abs(want - want_plain).max() > 0.05                           # the flag changes the picture
+
+
 def test_a_foveated_frame_against_the_python_path_tracer(oracle):
     """The three launches of render() -- periphery blocks, middle ring, fovea, each with its sample count, seeds from the
     launch index, subframe 0 for the inner two -- through tests/mini_pt.py: radiance AND layout of a whole foveated frame."""
