@@ -19,14 +19,43 @@ def tea4(v0, v1):                                                        # cuda/
     return v0
 
 
+def tex2d(tex, u, v):
+    """The fp32 contract standing in for tex2D<float4> (include/fovpt.h): bilinear, wrap, texel centres at +0.5, RGBA8 / 255."""
+    hh, ww = tex.shape
+    x, y = u * ww - 0.5, v * hh - 0.5
+    x0, y0 = int(np.floor(x)), int(np.floor(y))
+    fx, fy = x - x0, y - y0
+    out = np.zeros(3)
+    for yy, wy in ((y0, 1.0 - fy), (y0 + 1, fy)):
+        for xx, wx in ((x0, 1.0 - fx), (x0 + 1, fx)):
+            p = int(tex[yy % hh, xx % ww])
+            out += wx * wy * np.float64([p & 255, (p >> 8) & 255, (p >> 16) & 255]) / 255.0
+    return out
+
+
 class Scene:
     def __init__(self, model):
-        self.v0, self.e1, self.e2, self.mat = [], [], [], []
+        self.v0, self.e1, self.e2, self.mat, self.tc, self.tex = [], [], [], [], [], []
         for mesh in model.meshes:
             v = mesh.vertex.astype(np.float64)
+            textured = mesh.texture_id >= 0 and mesh.texcoord is not None
             for a, b, c in mesh.index:
                 self.v0.append(v[a]); self.e1.append(v[b] - v[a]); self.e2.append(v[c] - v[a]); self.mat.append(mesh.material)
+                self.tc.append(mesh.texcoord[[a, b, c]].astype(np.float64) if textured else None)
+                self.tex.append(model.textures[mesh.texture_id] if textured else None)
         self.v0, self.e1, self.e2 = np.array(self.v0), np.array(self.e1), np.array(self.e2)
+
+    def albedo(self, k, o, d):
+        """material colour, or the texture at the barycentric texcoord of the hit (deviceProgram.cu:655-665)"""
+        mat = self.mat[k]
+        if self.tex[k] is None:
+            return np.float64([mat.color.x, mat.color.y, mat.color.z])
+        p = np.cross(d, self.e2[k]); inv = 1.0 / float(np.dot(self.e1[k], p)); s = o - self.v0[k]
+        u = float(np.dot(s, p)) * inv
+        v = float(np.dot(np.cross(s, self.e1[k]), d)) * inv
+        t0, t1, t2 = self.tc[k]
+        tc = (1.0 - u - v) * t0 + u * t1 + v * t2
+        return tex2d(self.tex[k], tc[0], tc[1])
 
     def candidates(self, o, d):
         """Moeller-Trumbore against every triangle -> (t, det, valid) arrays; a candidate has tmin < t < tmax."""
@@ -147,7 +176,7 @@ def launch(model, probe, cam_uvw, eye, w, h, accum, doubtful, grid, factor, fill
                         doubt |= abs(facing) < 1e-6
                         N = n0 if facing >= 0.0 else -n0
                         P = o + t * d
-                        albedo = np.float64([mat.color.x, mat.color.y, mat.color.z])
+                        albedo = sc.albedo(k, o, d)
                         out_eta = (mat.eta if mat.eta != 0.0 else 2.0 / (1.0 - np.sqrt(0.08 * mat.specular)) - 1.0) if ray_eta == 1.0 else 1.0
                         wo = -d
                         # SampleLights

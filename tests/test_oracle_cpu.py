@@ -514,6 +514,25 @@ def test_shadow_catcher_against_the_python_path_tracer(oracle):
     assert np.abs(want - want_plain).max() > 0.05                           # the flag changes the picture
 
 
+def test_textured_scene_against_the_python_path_tracer(oracle):
+    """The procedural atrium (textured walls and floor, texcoords interpolated at the hit, bilinear wrap lookup; all-lobes
+    'application default' materials) through tests/mini_pt.py."""
+    import mini_pt
+    from common import cfg_uniform
+    model, cam = scenes.atrium(1500), scenes.ATRIUM_CAMERA
+    assert any(m.texture_id >= 0 for m in model.meshes)
+    w, h, spp, depth = 24, 14, 1, 3
+    S = oracle.OracleScene(model)
+    hp = oracle.HostProbe(scenes.ambient_probe(16, 8, 2.5))
+    F = oracle.OracleFrame(w, h, hp, cam)
+    oracle.render(S, F, cfg_uniform(spp, max_depth=depth))
+    uvw = oracle.camera_uvw(cam["eye"], cam["lookat"], cam["up"], cam["fovy"], w / h)
+    want, doubtful = mini_pt.render_uniform(model, hp, uvw, cam["eye"], w, h, spp, depth)
+    got = F.accum[..., :3].astype(np.float64)
+    err = np.abs(got - want).max(2) / np.maximum(np.abs(want).max(2), 0.05)
+    assert (err < 1e-3).mean() > 0.95 and np.median(err) < 1e-4, (float((err < 1e-3).mean()), float(np.median(err)), float(err[~doubtful].max()))
+
+
 def test_a_foveated_frame_against_the_python_path_tracer(oracle):
     """The three launches of render() -- periphery blocks, middle ring, fovea, each with its sample count, seeds from the
     launch index, subframe 0 for the inner two -- through tests/mini_pt.py: radiance AND layout of a whole foveated frame."""
