@@ -77,6 +77,8 @@ class Scene:
             return None
         tt = np.where(ok, t, np.inf)
         k = int(np.argmin(tt))                                            # argmin takes the lowest index among ties
+        tt2 = tt.copy(); tt2[k] = np.inf
+        self.near_tie = bool(tt2.min() - tt[k] <= 1e-6 * tt[k])          # coincident surfaces: binary32 may order them differently
         return k, float(tt[k])
 
     def occluded(self, o, d):                                            # any front-facing candidate (back faces culled, :241)
@@ -166,6 +168,7 @@ def launch(model, probe, cam_uvw, eye, w, h, accum, doubtful, grid, factor, fill
                     else:
                         k, t = hit
                         mat = sc.mat[k]
+                        doubt |= sc.near_tie
                         catcher = (mat.flags & 1) != 0                    # MATERIAL_FLAG_SHADOW_CATCHER (Material.h:9)
                     if hit is not None and catcher and secondary:
                         o = o + hit[1] * d                                # pass through, the bounce does not count (:646-651)

@@ -530,7 +530,8 @@ def test_textured_scene_against_the_python_path_tracer(oracle):
     want, doubtful = mini_pt.render_uniform(model, hp, uvw, cam["eye"], w, h, spp, depth)
     got = F.accum[..., :3].astype(np.float64)
     err = np.abs(got - want).max(2) / np.maximum(np.abs(want).max(2), 0.05)
-    assert (err < 1e-3).mean() > 0.95 and np.median(err) < 1e-4, (float((err < 1e-3).mean()), float(np.median(err)), float(err[~doubtful].max()))
+    # (one pixel looks at two coincident triangles that binary32 and binary64 order differently: flagged doubtful)
+    assert (err < 1e-3).mean() > 0.95 and np.median(err) < 1e-5 and err[~doubtful].max() < 1e-3, (float((err < 1e-3).mean()), float(err[~doubtful].max()))
 
 
 def test_a_foveated_frame_against_the_python_path_tracer(oracle):
