@@ -73,7 +73,8 @@ def bsdf_pdf(mat, eta_i, eta_o, N, V, L):
 def bsdf_eval(mat, albedo, eta_i, eta_o, N, V, L):
     ndl, ndv = _dot(N, L), _dot(N, V)
     h = L + V
-    H = h / np.linalg.norm(h, axis=1, keepdims=True)
+    with np.errstate(all="ignore"):
+        H = h / np.linalg.norm(h, axis=1, keepdims=True)
     ndh, ldh = _dot(N, H), _dot(L, H)
     lum = 0.3 * albedo[:, 0] + 0.6 * albedo[:, 1] + 0.1 * albedo[:, 2]
     with np.errstate(all="ignore"):

@@ -534,6 +534,46 @@ def test_textured_scene_against_the_python_path_tracer(oracle):
     assert (err < 1e-3).mean() > 0.95 and np.median(err) < 1e-5 and err[~doubtful].max() < 1e-3, (float((err < 1e-3).mean()), float(err[~doubtful].max()))
 
 
+_FUZZ_PY = range(int(os.environ.get("FOVPT_FUZZPY_FROM", "0")), int(os.environ.get("FOVPT_FUZZPY_TO", "10")))
+
+
+@pytest.mark.parametrize("seed", _FUZZ_PY)
+def test_random_scenes_against_the_python_path_tracer(oracle, seed):
+    """Seeded random triangle soups, materials over the whole range of every Disney parameter (eta 0 included: the
+    specular-derived index of refraction), random probes, cameras, sample counts and depths -- oracle against tests/mini_pt.py."""
+    import mini_pt
+    from common import cfg_uniform
+    rng = np.random.default_rng(1000 + seed)
+    meshes = []
+    for _ in range(int(rng.integers(2, 5))):
+        n = int(rng.integers(3, 14))
+        centre = rng.uniform(-1.5, 1.5, (n, 1, 3))
+        tri = (centre + rng.uniform(-1.2, 1.2, (n, 3, 3))).astype(np.float32)
+        m = abi.Material.reference_default()
+        m.color.set(tuple(rng.uniform(0.0, 1.0, 3))); m.emission.set(tuple(rng.uniform(0.0, 1.5, 3) * (rng.random() < 0.5)))
+        m.eta = float(rng.choice([0.0, 1.0, 1.2, 1.5, 2.4])); m.metallic = float(rng.uniform(0, 1)); m.subsurface = float(rng.choice([0.0, rng.uniform(0, 1)]))
+        m.specular = float(rng.uniform(0, 1)); m.roughness = float(rng.choice([0.0, 0.05, rng.uniform(0.1, 1.0)])); m.specularTint = float(rng.uniform(0, 1))
+        m.clearcoat = float(rng.choice([0.0, rng.uniform(0, 1)])); m.clearcoatGloss = float(rng.uniform(0, 1))
+        m.transmission = float(rng.choice([0.0, 1.0, rng.uniform(0, 1)]))
+        meshes.append(scenes.TriangleMesh(vertex=tri.reshape(-1, 3), index=np.arange(3 * n, dtype=np.uint32).reshape(n, 3), material=m))
+    model = scenes.Model(meshes=meshes)
+    cam = dict(eye=tuple(rng.uniform(-1, 1, 3) + np.float64([0, 0, 7])), lookat=tuple(rng.uniform(-0.5, 0.5, 3)), up=(0.0, 1.0, 0.0), fovy=float(rng.uniform(25, 60)))
+    w, h, spp, depth = int(rng.integers(10, 18)), int(rng.integers(8, 14)), int(rng.integers(1, 4)), int(rng.integers(1, 5))
+    S = oracle.OracleScene(model)
+    hp = oracle.HostProbe(scenes.sky_probe(16, 8, seed=seed) if rng.random() < 0.7 else scenes.ambient_probe(8, 4, float(rng.uniform(0.1, 3.0))))
+    F = oracle.OracleFrame(w, h, hp, cam)
+    oracle.render(S, F, cfg_uniform(spp, max_depth=depth))
+    uvw = oracle.camera_uvw(cam["eye"], cam["lookat"], cam["up"], cam["fovy"], w / h)
+    want, doubtful = mini_pt.render_uniform(model, hp, uvw, cam["eye"], w, h, spp, depth)
+    got = F.accum[..., :3].astype(np.float64)
+    fin = np.isfinite(want).all(2) & np.isfinite(got).all(2)
+    assert np.array_equal(np.isfinite(want).all(2) | doubtful, np.isfinite(got).all(2) | doubtful)
+    err = np.abs(got - want).max(2) / np.maximum(np.abs(want).max(2), 0.05)
+    sure = fin & ~doubtful
+    assert sure.mean() > 0.5
+    assert (err[sure] < 2e-3).mean() > 0.97 and np.median(err[sure]) < 1e-4, (seed, float((err[sure] < 2e-3).mean()), float(np.median(err[sure])), float(err[sure].max()))
+
+
 def test_a_foveated_frame_against_the_python_path_tracer(oracle):
     """The three launches of render() -- periphery blocks, middle ring, fovea, each with its sample count, seeds from the
     launch index, subframe 0 for the inner two -- through tests/mini_pt.py: radiance AND layout of a whole foveated frame."""
