@@ -555,6 +555,7 @@ def test_random_scenes_against_the_python_path_tracer(oracle, seed):
         m.specular = float(rng.uniform(0, 1)); m.roughness = float(rng.choice([0.0, 0.05, rng.uniform(0.1, 1.0)])); m.specularTint = float(rng.uniform(0, 1))
         m.clearcoat = float(rng.choice([0.0, rng.uniform(0, 1)])); m.clearcoatGloss = float(rng.uniform(0, 1))
         m.transmission = float(rng.choice([0.0, 1.0, rng.uniform(0, 1)]))
+        m.flags = abi.MATERIAL_FLAG_SHADOW_CATCHER if rng.random() < 0.2 else 0
         meshes.append(scenes.TriangleMesh(vertex=tri.reshape(-1, 3), index=np.arange(3 * n, dtype=np.uint32).reshape(n, 3), material=m))
     model = scenes.Model(meshes=meshes)
     cam = dict(eye=tuple(rng.uniform(-1, 1, 3) + np.float64([0, 0, 7])), lookat=tuple(rng.uniform(-0.5, 0.5, 3)), up=(0.0, 1.0, 0.0), fovy=float(rng.uniform(25, 60)))
