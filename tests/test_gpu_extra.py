@@ -388,6 +388,38 @@ def test_small_geometry_seen_from_far_away(oracle):
 
 
 @pytest.mark.gpu
+def test_library_frames_against_the_python_path_tracer():
+    """The product against tests/mini_pt.py directly, no oracle in between: the independent binary64 Python statement of the
+    path (its own RNG, camera rays, brute-force hits, Disney BSDF, probe sampling, path loop, foveated launches) predicts the
+    radiance the library renders -- uniform and three-pass foveated frames of the Cornell box with a shadow-catching floor."""
+    import types
+    import mini_pt
+    model, cam = scenes.cornell_box(), scenes.CORNELL_CAMERA
+    model.meshes[0].material.flags = abi.MATERIAL_FLAG_SHADOW_CATCHER      # floor + ceiling + back wall
+    probe_data = scenes.sky_probe(16, 8, seed=6)
+    for foveated in (False, True):
+        w, h = (20, 20) if not foveated else (48, 32)
+        cfg = cfg_uniform(2, max_depth=3) if not foveated else cfg_foveated(5, 11, (1, 2, 3), max_depth=3)
+        gaze = (27, 14)
+        r = make_gpu(model, probe_data, cam, (w, h), cfg, gaze=gaze, subframe_index=2)
+        pd = renderer.ProbeData(probe_data).BuildCDF()
+        hp = types.SimpleNamespace(data=pd.data, pdfx=pd.pdfValuesX, cdfx=pd.cdfValuesX, pdfy=pd.pdfValuesY, cdfy=pd.cdfValuesY)
+        c = r.launchParams.camera
+        uvw = [np.float64([v.x, v.y, v.z]) for v in (c.U, c.V, c.W)]
+        r.render()
+        got = r.downloadAccum().astype(np.float64)
+        r.close()
+        if foveated:
+            want, doubtful = mini_pt.render_foveated(model, hp, uvw, cam["eye"], w, h, gaze, 5, 11, (1, 2, 3), 2, 3)
+        else:
+            want, doubtful = mini_pt.render_uniform(model, hp, uvw, cam["eye"], w, h, 2, 3)
+        written = ~np.isnan(want[..., 0])
+        assert np.array_equal(written, got[..., 3] == 1.0)
+        err = np.abs(got[..., :3][written] - want[written]).max(1) / np.maximum(np.abs(want[written]).max(1), 0.05)
+        assert (err < 1e-3).mean() > 0.97 and err[~doubtful[written]].max() < 1e-3 and np.median(err) < 1e-5, (foveated, float(np.median(err)))
+
+
+@pytest.mark.gpu
 def test_hierarchy_choice_does_not_change_the_frame(oracle, monkeypatch):
     """Hits are defined without reference to the hierarchy (closest t, lowest primitive id): the plain Karras
     LBVH (FOVPT_BVH=lbvh, the A/B path of fovpt_set_scene) must give the oracle's frame just as PLOC does."""
