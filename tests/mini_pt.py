@@ -97,6 +97,8 @@ class ProbeF64:
         phi = 0.0 if (d[0] == 0.0 and d[2] == 0.0) else np.arctan2(d[2], d[0])
         u, v = (np.pi + phi) / (2.0 * np.pi), theta / np.pi
         px = min(max(int(u * self.w), 0), self.w - 1); py = min(max(int(v * self.h), 0), self.h - 1)
+        fu, fv = u * self.w, v * self.h
+        self.near_texel_edge = min(abs(fu - round(fu)), abs(fv - round(fv))) < 1e-5      # binary32 may land in the neighbouring texel
         return self.data[py, px, :3]
 
     def sample(self, rnd):                                               # ProbeSample, Probe.cuh:138-169
@@ -158,6 +160,7 @@ def launch(model, probe, cam_uvw, eye, w, h, accum, doubtful, grid, factor, fill
                 d /= np.linalg.norm(d)
                 o = eye.copy()
                 backplate = pr.eval_dir(d)
+                doubt |= pr.near_texel_edge
                 thr, ray_eta, done, secondary, depth = np.ones(3), 1.0, False, False, 0
                 direct, indirect, alpha = np.zeros(3), np.zeros(3), np.zeros(3)
                 while True:

@@ -575,6 +575,38 @@ def test_random_scenes_against_the_python_path_tracer(oracle, seed):
     assert (err[sure] < 2e-3).mean() > 0.97 and np.median(err[sure]) < 1e-4, (seed, float((err[sure] < 2e-3).mean()), float(np.median(err[sure])), float(err[sure].max()))
 
 
+_FUZZ_PYF = range(int(os.environ.get("FOVPT_FUZZPYF_FROM", "0")), int(os.environ.get("FOVPT_FUZZPYF_TO", "4")))
+
+
+@pytest.mark.parametrize("seed", _FUZZ_PYF)
+def test_random_foveated_frames_against_the_python_path_tracer(oracle, seed):
+    """Random frame sizes, gaze points (also off the frame: wrapping offsets), radii, per-pass sample counts, subframe
+    indices and depths: the three launches of render() in the oracle and in tests/mini_pt.py."""
+    import mini_pt
+    rng = np.random.default_rng(500 + seed)
+    model, cam = scenes.cornell_box(), scenes.CORNELL_CAMERA
+    w, h = 4 * int(rng.integers(6, 13)), 4 * int(rng.integers(5, 9))
+    gaze = (int(rng.integers(-3, w + 3)), int(rng.integers(-3, h + 3)))
+    ri = int(rng.integers(2, 7)); ro = ri + int(rng.integers(2, 9))
+    spp = tuple(int(x) for x in rng.integers(1, 4, 3))
+    subframe, depth = int(rng.integers(0, 6)), int(rng.integers(1, 4))
+    S = oracle.OracleScene(model)
+    hp = oracle.HostProbe(scenes.sky_probe(16, 8, seed=seed))
+    F = oracle.OracleFrame(w, h, hp, cam, gaze=gaze, subframe_index=subframe)
+    oracle.render(S, F, cfg_foveated(ri, ro, spp, max_depth=depth))
+    uvw = oracle.camera_uvw(cam["eye"], cam["lookat"], cam["up"], cam["fovy"], w / h)
+    want, doubtful = mini_pt.render_foveated(model, hp, uvw, cam["eye"], w, h, gaze, ri, ro, spp, subframe, depth)
+    written = ~np.isnan(want[..., 0])
+    assert np.array_equal(written, F.accum[..., 3] == 1.0), (seed, gaze, ri, ro)
+    sure = written & ~doubtful
+    got = F.accum[..., :3].astype(np.float64)[sure]
+    err = np.abs(got - want[sure]).max(1) / np.maximum(np.abs(want[sure]).max(1), 0.05)
+    if written.sum() >= 50:                                              # (a gaze point off the frame can leave it almost empty)
+        assert sure.sum() > 0.5 * written.sum()
+    if sure.any():
+        assert (err < 1e-3).mean() > 0.97 and np.median(err) < 1e-5, (seed, float((err < 1e-3).mean()), float(np.median(err)))
+
+
 def test_a_foveated_frame_against_the_python_path_tracer(oracle):
     """The three launches of render() -- periphery blocks, middle ring, fovea, each with its sample count, seeds from the
     launch index, subframe 0 for the inner two -- through tests/mini_pt.py: radiance AND layout of a whole foveated frame."""
