@@ -9,7 +9,8 @@
  * (SURVEY.md section 4), and it cannot be built in this image (it needs the OptiX SDK
  * headers, the CUDA toolkit and an RT driver; writing stand-ins for them is not allowed).
  * This file is therefore a line-by-line restatement from reading the reference source, each
- * function citing the file:line it follows.  The arithmetic the reference delegates to
+ * function citing the file:line it follows; tests/mini_pt.py is a second, independent statement
+ * of the same path (scalar Python, binary64) that tests/test_oracle_cpu.py holds it against.  The arithmetic the reference delegates to
  * third-party code that is not under /root/reference is defined HERE as the parity contract:
  *   - NVIDIA OptiX 7/8 triangle intersection + traversal ("OptiX SDK 8.0", README.md:2;
  *     call sites PT_sv5_/deviceProgram.cu:209,234): Moeller-Trumbore in fp32, see
