@@ -282,6 +282,58 @@ def test_bistro_class_scene_full_size_against_oracle(oracle):
     assert st.paths == cnt[2] == 1726659          # paths per frame of C4
 
 
+def test_c5_stereo_bistro_class_full_size_against_oracle(oracle):
+    """BASELINE.json configs[4] at full size on one GPU: ~3.8 M triangles, stereo 2 x 2160x2160 (two cameras
+    +-32 mm apart with OpenXR-style off-centre frusta, two render() calls per frame as in
+    OtherProjects_01/11HelloRaytracingOpenXR/main.cpp:892-955), per-eye foveation with radii 296/964, gaze at the
+    eye's frame centre, depth 8.  Both eyes bit-exact against the oracle; 3,654,059 paths per eye."""
+    W = H = 2160
+    model = scenes.atrium(3800000, material="app")
+    cfg = cfg_foveated(296, 964, (1, 2, 8), max_depth=8)
+    probe = scenes.ambient_probe(W, H, 2.5)
+    cam = scenes.ATRIUM_CAMERA
+    r = make_gpu(model, probe, cam, (W, H), cfg)
+    S, F = make_oracle(oracle, model, probe, cam, (W, H))
+    fwd = np.array(cam["lookat"], np.float64) - np.array(cam["eye"], np.float64)
+    right = np.cross(fwd, np.array(cam["up"], np.float64))
+    right /= np.linalg.norm(right)
+    total_rays = 0
+    for side, (al, ar) in ((-1.0, (-0.85, 0.70)), (1.0, (-0.70, 0.85))):        # XrFovf angleLeft/Right, radians
+        eye = tuple(np.array(cam["eye"], np.float64) + side * 3.2 * right)        # +-32 mm in the scene's cm
+        r.setCameraFov(eye, fwd, cam["up"], al, ar, 0.78, -0.78)
+        F.lp.camera = r.launchParams.camera
+        for lp in (r.launchParams, F.lp):
+            lp.frame.subframe_index = 0
+        r.reset_stats()
+        r.render()
+        ga, gf = r.downloadAccum(), r.downloadPixels()
+        st = r.stats()
+        cnt = oracle.render(S, F, cfg, nthreads=min(32, os.cpu_count() or 1))
+        l2, bits, px = compare_frames(ga, gf, F.accum, F.frame)
+        assert l2 <= 1e-4 and bits == 0 and px == 0, (side, l2, bits, px)
+        assert st.paths == cnt[2] == 3654059, (st.paths, cnt[2])
+        assert np.isfinite(ga).all()
+        total_rays += st.radiance_rays + st.shadow_rays
+    assert total_rays > 2 * 3654059
+    r.close()
+
+
+def test_c1_cornell_full_size_against_oracle(oracle):
+    """BASELINE.json configs[0] at full size: Cornell box (32 triangles), 512x512, uniform 4 spp, depth 3."""
+    model, probe = scenes.cornell_box(), scenes.ambient_probe(64, 32, 0.2)
+    assert model.num_triangles == 32
+    cfg = cfg_uniform(4, 3)
+    r = make_gpu(model, probe, scenes.CORNELL_CAMERA, (512, 512), cfg)
+    r.render()
+    ga, gf, st = r.downloadAccum(), r.downloadPixels(), r.stats()
+    r.close()
+    S, F = make_oracle(oracle, model, probe, scenes.CORNELL_CAMERA, (512, 512))
+    cnt = oracle.render(S, F, cfg, nthreads=min(32, os.cpu_count() or 1))
+    l2, bits, px = compare_frames(ga, gf, F.accum, F.frame)
+    assert l2 <= 1e-4 and bits == 0 and px == 0, (l2, bits, px)
+    assert st.paths == cnt[2] == 512 * 512 * 4
+
+
 def test_obj_loaded_textured_scene(oracle, tmp_path):
     """OBJ + MTL + map_Kd through loaders.load_obj (loadOBJ semantics), rendered and checked: exercises the
     textured-albedo path (barycentric texcoords + bilinear fetch, deviceProgram.cu:655-670) on real loader output."""
