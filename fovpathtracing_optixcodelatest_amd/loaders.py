@@ -332,6 +332,89 @@ def _corner(tok: str, nv: int, nt: int, nn: int) -> Tuple[int, int, int]:
     return v, vn, vt
 
 
+def _triangulate(cs: list, pos: list) -> list:
+    """Polygon -> triangles the way the reference's OBJ reader does it (tinyobjloader 2.0.0-rc, vendored under
+    support/tinyobjloader and called with triangulate = true, Model.cpp:150-157): ear clipping in binary32 on the
+    projection onto the two axes chosen from the first non-degenerate corner; a convex planar quad comes out as the
+    fan (0,1,2) (0,2,3), concave and non-planar polygons do not.  Corners are (v, vn, vt) index triples."""
+    n = len(cs)
+    if n < 3:
+        return []
+    if n == 3:
+        return [tuple(cs)]
+    f32 = np.float32
+    eps = f32(np.finfo(np.float32).eps)
+    P = [tuple(f32(x) for x in pos[c[0]]) if 0 <= c[0] < len(pos) else None for c in cs]
+    axes = [1, 2]
+    for k in range(n):
+        p0, p1, p2 = P[k], P[(k + 1) % n], P[(k + 2) % n]
+        if p0 is None or p1 is None or p2 is None:
+            continue
+        e0 = [p1[a] - p0[a] for a in range(3)]
+        e1 = [p2[a] - p1[a] for a in range(3)]
+        cx = abs(e0[1] * e1[2] - e0[2] * e1[1])
+        cy = abs(e0[2] * e1[0] - e0[0] * e1[2])
+        cz = abs(e0[0] * e1[1] - e0[1] * e1[0])
+        if cx > eps or cy > eps or cz > eps:
+            if not (cx > cy and cx > cz):
+                axes[0] = 0
+                if cz > cx and cz > cy:
+                    axes[1] = 1
+            break
+    area = f32(0)
+    for k in range(n):
+        p0, p1 = P[k], P[(k + 1) % n]
+        if p0 is None or p1 is None:
+            continue
+        area = area + (p0[axes[0]] * p1[axes[1]] - p0[axes[1]] * p1[axes[0]]) * f32(0.5)
+    rem = list(range(n))                                    # positions in cs of the remaining polygon
+    out = []
+    guess = 0
+    remaining_iter = n
+    prev_n = n
+    while len(rem) > 3 and remaining_iter > 0:
+        m = len(rem)
+        if guess >= m:
+            guess -= m
+        if prev_n != m:
+            prev_n = m
+            remaining_iter = m
+        else:
+            remaining_iter -= 1
+        ind = [rem[(guess + k) % m] for k in range(3)]
+        vx = [P[i][axes[0]] if P[i] is not None else f32(0) for i in ind]
+        vy = [P[i][axes[1]] if P[i] is not None else f32(0) for i in ind]
+        cross = (vx[1] - vx[0]) * (vy[2] - vy[1]) - (vy[1] - vy[0]) * (vx[2] - vx[1])
+        if cross * area < 0:
+            guess += 1
+            continue
+        overlap = False
+        for other in range(3, m):
+            q = P[rem[(guess + other) % m]]
+            if q is None:
+                continue
+            tx, ty = q[axes[0]], q[axes[1]]
+            c = False
+            j = 2
+            for i in range(3):                             # pnpoly on the candidate ear
+                if (vy[i] > ty) != (vy[j] > ty):
+                    with np.errstate(all="ignore"):
+                        if tx < (vx[j] - vx[i]) * (ty - vy[i]) / (vy[j] - vy[i]) + vx[i]:
+                            c = not c
+                j = i
+            if c:
+                overlap = True
+                break
+        if overlap:
+            guess += 1
+            continue
+        out.append((cs[ind[0]], cs[ind[1]], cs[ind[2]]))
+        del rem[(guess + 1) % m]
+    if len(rem) == 3:
+        out.append((cs[rem[0]], cs[rem[1]], cs[rem[2]]))
+    return out
+
+
 def load_obj(obj_file: str) -> Model:
     model_dir = os.path.dirname(obj_file)
     pos: List[Tuple[float, float, float]] = []
@@ -363,8 +446,8 @@ def load_obj(obj_file: str) -> Model:
                 tex.append((float(t[1]), float(t[2]) if len(t) > 2 else 0.0))
             elif k == "f":
                 cs = [_corner(x, len(pos), len(tex), len(nrm)) for x in t[1:]]
-                for i in range(1, len(cs) - 1):                 # fan from the first corner
-                    cur["faces"].append((cs[0], cs[i], cs[i + 1]))
+                for tri in _triangulate(cs, pos):
+                    cur["faces"].append(tri)
                     cur["mats"].append(cur_mat)
             elif k in ("o", "g"):
                 flush()
@@ -386,10 +469,15 @@ def load_obj(obj_file: str) -> Model:
     T = np.asarray(tex, np.float32).reshape(-1, 2)
 
     model = Model()
-    known_textures: Dict[str, int] = {}
     for shape in shapes:
+        # Both maps live per SHAPE in the reference (Model.cpp:174-175), not per mesh and not per model:
+        #  * a texture named by two shapes is loaded twice and gets two ids;
+        #  * a corner that an earlier material of the same shape already added keeps the id it got in THAT mesh --
+        #    the later mesh then indexes its own vertex array with it (a quirk of the reference, reproduced; if the
+        #    id is out of range for the later mesh the reference reads out of bounds and fovpt_set_scene rejects it).
+        known: Dict[Tuple[int, int, int], int] = {}
+        known_textures: Dict[str, int] = {}
         for mid in sorted(set(shape["mats"])):                  # std::set<int>: ascending
-            known: Dict[Tuple[int, int, int], int] = {}
             vtx: List[np.ndarray] = []
             nrms: List[np.ndarray] = []
             tcs: List[np.ndarray] = []

@@ -100,3 +100,38 @@ def test_atrium_foveated_textured(oracle):
     assert bits == 0 and px == 0, (l2, bits, px)
     assert st.paths == cnt[2]
     assert np.isfinite(ga).all()
+
+
+def test_device_math_against_the_reference_vectors():
+    """The GPU's transcendental functions (include/fovpt_detmath.h, FOVPT_OP_*) against outputs of THE REFERENCE'S OWN
+    CODE (tests/golden/ref_vectors.npz: Probe.cuh ProbeDirToUV / ProbeUVToDir and cuda/helpers.h toSRGB compiled from
+    /root/reference with the host libm): within the libm-vs-correctly-rounded budget, 4e-7 absolute on O(1) values."""
+    import os
+    from fovpathtracing_optixcodelatest_amd import renderer
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_vectors.npz"))
+    r = renderer.SampleRenderer(scenes.cornell_box())
+    f32 = np.float32
+    kPi = f32(3.141592653589793)
+    kInvPi = f32(1.0) / kPi
+    # ProbeDirToUV (Probe.cuh:38-46)
+    d = z["in:probe/dirs"]
+    theta = r.debug_math(abi.OP_ACOS, np.clip(d[:, 1], -1, 1).astype(f32))
+    phi = r.debug_math(abi.OP_ATAN2, np.ascontiguousarray(d[:, 2]), np.ascontiguousarray(d[:, 0]))
+    phi[(d[:, 0] == 0) & (d[:, 2] == 0)] = 0
+    u = ((kPi + phi) * kInvPi * f32(0.5)).astype(f32)
+    v = (theta * kInvPi).astype(f32)
+    want = z["out:probe/dir_to_uv"]
+    assert np.abs(u - want[:, 0]).max() <= 4e-7 and np.abs(v - want[:, 1]).max() <= 4e-7
+    # ProbeUVToDir (Probe.cuh:48-58)
+    uv = z["in:probe/uv"]
+    th, ph = (uv[:, 1] * kPi).astype(f32), (uv[:, 0] * f32(2.0) * kPi).astype(f32)
+    st, ct = r.debug_math(abi.OP_SIN, th), r.debug_math(abi.OP_COS, th)
+    sp, cp = r.debug_math(abi.OP_SIN, ph), r.debug_math(abi.OP_COS, ph)
+    got = np.stack([-st * cp, ct, -st * sp], axis=1).astype(f32)
+    assert np.abs(got - z["out:probe/uv_to_dir"]).max() <= 4e-7
+    # toSRGB (cuda/helpers.h:35-43)
+    c = np.clip(z["in:color/rgb"], 0, 1).astype(f32).reshape(-1)
+    powed = r.debug_math(abi.OP_POW, c, np.full_like(c, f32(1.0) / f32(2.4)))
+    srgb = np.where(c < f32(0.0031308), f32(12.92) * c, f32(1.055) * powed - f32(0.055)).astype(f32)
+    assert np.abs(srgb - z["out:color/to_srgb"].reshape(-1)).max() <= 4e-7
+    r.close()

@@ -73,10 +73,12 @@ def test_obj_materials_are_ctor_defaults_with_color_and_emission(obj_dir):
         assert (mat.transmission, mat.metallic, mat.eta, mat.roughness) == pytest.approx((0.4, 0.5, 1.4, 1.0))
 
 
-def test_obj_diffuse_texture_is_loaded_once_and_mirrored(obj_dir):
+def test_obj_diffuse_texture_is_loaded_once_per_shape_and_mirrored(obj_dir):
     m = loaders.load_obj(os.path.join(obj_dir, "test.obj"))
-    assert len(m.textures) == 1
-    assert m.meshes[0].texture_id == 0 and m.meshes[2].texture_id == 0 and m.meshes[1].texture_id == -1
+    # knownTextures lives per shape (Model.cpp:175): the two shapes that use tex.ppm each load their own copy
+    # (checked against the compiled reference in tests/test_ref_pin_cpu.py)
+    assert len(m.textures) == 2 and np.array_equal(m.textures[0], m.textures[1])
+    assert m.meshes[0].texture_id == 0 and m.meshes[2].texture_id == 1 and m.meshes[1].texture_id == -1
     t = m.textures[0]
     assert t.shape == (2, 2)
     # file rows were [R G] / [B W]; after the y mirror row 0 is [B W]
@@ -96,7 +98,7 @@ def test_loaded_model_packs_for_the_c_abi(obj_dir):
     from fovpathtracing_optixcodelatest_amd.scenes import pack_model
     m = loaders.load_obj(os.path.join(obj_dir, "test.obj"))
     md, n, td, nt, keep = pack_model(m)
-    assert n == 3 and nt == 1 and md[0].num_triangles == 2 and md[0].texture_id == 0 and td[0].width == 2
+    assert n == 3 and nt == 2 and md[0].num_triangles == 2 and md[0].texture_id == 0 and td[0].width == 2
 
 
 # ---- Radiance .hdr environment maps (loadProbe, PT_sv5_/main.cpp:160-171 -> stbi_loadf) ---------------
@@ -352,7 +354,7 @@ def test_obj_with_png_and_tga_textures(tmp_path):
     (tmp_path / "b.tga").write_bytes(_tga(4, 6, 2, 24, t.tobytes()))
     (tmp_path / "m.mtl").write_text("newmtl A\nKd 1 1 1\nmap_Kd a.png\nnewmtl B\nKd 1 1 1\nmap_Kd b.tga\nnewmtl C\nKd 1 1 1\nmap_Kd missing.jpg\n")
     (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\n"
-                                    "usemtl A\nf 1/1 2/2 3/3\nusemtl B\nf 1/1 2/2 3/3\nusemtl C\nf 1/1 2/2 3/3\n")
+                                    "g a\nusemtl A\nf 1/1 2/2 3/3\ng b\nusemtl B\nf 1/1 2/2 3/3\ng c\nusemtl C\nf 1/1 2/2 3/3\n")
     model = loaders.load_obj(str(tmp_path / "m.obj"))
     ids = [m.texture_id for m in model.meshes]
     assert ids == [0, 1, -1]
