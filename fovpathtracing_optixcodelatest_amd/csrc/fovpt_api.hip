@@ -124,7 +124,7 @@ hipEvent_t get_event(fovpt_ctx* c)
 {
     if (!c->free_events.empty()) { hipEvent_t e = c->free_events.back(); c->free_events.pop_back(); return e; }
     hipEvent_t e = nullptr;
-    (void)hipEventCreate(&e);
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;      // (Timed skips the measurement)
     return e;
 }
 
@@ -132,11 +132,15 @@ struct Timed {
     fovpt_ctx* c; int kind; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
     Timed(fovpt_ctx* c_, int k, hipStream_t s = nullptr) : c(c_), kind(k), st(s ? s : c_->stream)
     {
-        if (c->cfg.profile) { a = get_event(c); b = get_event(c); (void)hipEventRecord(a, st); }
+        if (c->cfg.profile) {
+            a = get_event(c); b = get_event(c);
+            if (a && b) (void)hipEventRecord(a, st);
+            else { if (a) c->free_events.push_back(a); if (b) c->free_events.push_back(b); a = b = nullptr; }
+        }
     }
     ~Timed()
     {
-        if (c->cfg.profile) { (void)hipEventRecord(b, st); EventPair p = {a, b, kind}; c->pending.push_back(p); }
+        if (a && b) { (void)hipEventRecord(b, st); EventPair p = {a, b, kind}; c->pending.push_back(p); }
     }
 };
 
@@ -200,10 +204,14 @@ int ensure_state(fovpt_ctx* c, StateSet& S, size_t slots, size_t launches)
     return FOVPT_OK;
 }
 
-int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_in, int npass, int chunked);
+int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_in, int npass, int chunked, int whole_frame);
 
 // The engine: all passes of one frame as one wavefront job (or several, for very large launches).
-int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_in, int npass)
+// whole_frame: the passes are a complete frame (fovpt_render), so with world > 1 the pixels nobody writes are
+// cleared on the ranks other than 0 (rank 0 keeps them, as the reference's frame buffer keeps what no launch
+// overwrites): the sum over the ranks is then the single-GPU frame.  A single fovpt_launch leaves them alone on
+// every rank -- it may be one of several launches that make up the caller's frame.
+int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_in, int npass, int whole_frame)
 {
     if (!c->has_scene || lp->traversable != c->scene_id) return fail(c, FOVPT_E_NO_SCENE, "launch without a scene (traversable %llu, current %llu)",
                                                                      (unsigned long long)lp->traversable, (unsigned long long)c->scene_id);
@@ -225,25 +233,30 @@ int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passe
     const uint64_t budget = c->slot_budget;
     if (all_slots > budget) {
         c->stats.frames++;
-        if (c->cfg.world > 1) {
-            // foreign pixels are written as zero by whichever job wins them; holes must not keep stale sums
+        const size_t npix = (size_t)lp->frame.size.x * lp->frame.size.y;
+        // Accumulate mode blends with the pixel's value from BEFORE the launch (a pass of render() = one
+        // optixLaunch).  The chunks of a pass are separate jobs, so a pixel that two of them write (clamped
+        // or overlapping fills) would otherwise be blended twice: keep a copy for the chunks to read.  The copy
+        // of the FIRST pass is taken here, before anything of this frame touches the buffer (the clearing below
+        // included); render() blends in pass P only, which is the first.
+        auto blends = [&](const PassDev& P) { return c->cfg.accumulate && P.subframe > 0 && !P.redraw; };
+        auto snapshot = [&]() -> int {
+            HIPCHK(c, c->accum_before.reserve(npix * 16));
+            HIPCHK(c, hipMemcpyAsync(c->accum_before.p, lp->frame.accum_buffer, npix * 16, hipMemcpyDeviceToDevice, c->shadow_stream));
+            return FOVPT_OK;
+        };
+        if (npass > 0 && blends(passes_in[0])) { int rc = snapshot(); if (rc) return rc; }
+        if (whole_frame && c->cfg.world > 1 && c->cfg.rank != 0) {
+            // The chunk jobs zero the pixels whose last writer (within the chunk) belongs to another rank; pixels no
+            // chunk writes must not keep this rank's stale values (rank 0 keeps its own, like the unchunked path)
             // (on the stream the resolves run on: after the previous frame's, before this frame's)
-            HIPCHK(c, hipMemsetAsync(lp->frame.frame_buffer, 0, (size_t)lp->frame.size.x * lp->frame.size.y * 4, c->shadow_stream));
-            HIPCHK(c, hipMemsetAsync(lp->frame.accum_buffer, 0, (size_t)lp->frame.size.x * lp->frame.size.y * 16, c->shadow_stream));
+            HIPCHK(c, hipMemsetAsync(lp->frame.frame_buffer, 0, npix * 4, c->shadow_stream));
+            HIPCHK(c, hipMemsetAsync(lp->frame.accum_buffer, 0, npix * 16, c->shadow_stream));
         }
         for (int p = 0; p < npass; p++) {
             const PassDev& P = passes_in[p];
-            // Accumulate mode blends with the pixel's value from BEFORE the launch (a pass of render() = one
-            // optixLaunch).  The chunks of a pass are separate jobs, so a pixel that two of them write (clamped
-            // or overlapping fills) would otherwise be blended twice: keep a copy for the chunks to read.
-            if (c->cfg.accumulate && P.subframe > 0 && !P.redraw) {
-                const size_t nb = (size_t)lp->frame.size.x * lp->frame.size.y * 16;
-                HIPCHK(c, c->accum_before.reserve(nb));
-                HIPCHK(c, hipMemcpyAsync(c->accum_before.p, lp->frame.accum_buffer, nb, hipMemcpyDeviceToDevice, c->shadow_stream));
-                c->use_accum_before = true;
-            } else {
-                c->use_accum_before = false;
-            }
+            c->use_accum_before = blends(P);
+            if (p > 0 && c->use_accum_before) { int rc = snapshot(); if (rc) return rc; }      // (no caller of this library gets here)
             const uint64_t per_row = (uint64_t)P.gw * P.spp;
             if (per_row == 0 || P.gh == 0) continue;
             if (per_row > budget) return fail(c, FOVPT_E_INVALID, "one launch row needs %llu sample slots (budget %llu)", (unsigned long long)per_row, (unsigned long long)budget);
@@ -251,7 +264,7 @@ int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passe
             for (uint32_t y0 = 0; y0 < P.gh; y0 += rows_per) {
                 PassDev Q = P;
                 Q.row0 = y0; Q.row1 = y0 + rows_per < P.gh ? y0 + rows_per : P.gh;
-                int rc = run_job(c, lp, &Q, 1, 1);
+                int rc = run_job(c, lp, &Q, 1, 1, 0);
                 if (rc) return rc;
             }
         }
@@ -260,15 +273,16 @@ int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passe
     PassDev full[FOVPT_MAX_PASSES];
     for (int p = 0; p < npass; p++) { full[p] = passes_in[p]; full[p].row0 = 0; full[p].row1 = passes_in[p].gh; }
     c->stats.frames++;
-    return run_job(c, lp, full, npass, 0);
+    return run_job(c, lp, full, npass, 0, whole_frame);
 }
 
 // One wavefront job: generate -> (closest, shade, occlusion) x depth -> resolve over the given passes / row ranges.
-int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_in, int npass, int chunked)
+int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_in, int npass, int chunked, int whole_frame)
 {
     FrameDev fd;
     memset(&fd, 0, sizeof(fd));
     fd.chunked = chunked;
+    fd.zero_holes = (whole_frame && !chunked && c->cfg.world > 1 && c->cfg.rank != 0) ? 1 : 0;
     uint64_t slots = 0, launches = 0;
     for (int p = 0; p < npass; p++) {
         PassDev P = passes_in[p];
@@ -423,7 +437,7 @@ int fovpt_create(fovpt_ctx** out, int device)
         }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&S.ev_done, hipEventDefault);
     }
-    if (e != hipSuccess) { delete c; return fail(nullptr, FOVPT_E_DEVICE, "stream/event creation: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { fovpt_destroy(c); return fail(nullptr, FOVPT_E_DEVICE, "stream/event creation: %s", hipGetErrorString(e)); }
     *out = c;
     return FOVPT_OK;
 }
@@ -432,8 +446,8 @@ void fovpt_destroy(fovpt_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
-    (void)hipStreamSynchronize(c->shadow_stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->shadow_stream) (void)hipStreamSynchronize(c->shadow_stream);
     drain_events(c);
     for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
     for (StateSet& S : c->set) {
@@ -445,11 +459,11 @@ void fovpt_destroy(fovpt_ctx* c)
         for (DevBuf* b : S.all()) b->release();
     }
     free_scene(c);
-    DevBuf* bufs[] = {&c->tri_tc, &c->meshes, &c->textures, &c->pr_data, &c->pr_pdfx, &c->pr_cdfx, &c->pr_pdfy, &c->pr_cdfy,
+    DevBuf* bufs[] = {&c->tri_tc, &c->meshes, &c->textures, &c->pr_data, &c->pr_pdfx, &c->pr_cdfx, &c->pr_pdfy, &c->pr_cdfy, &c->pr_guidex, &c->pr_guidey,
                       &c->fb_frame, &c->fb_accum, &c->fb_color, &c->fb_normal, &c->fb_albedo, &c->accum_before};
     for (DevBuf* b : bufs) b->release();
-    (void)hipStreamDestroy(c->stream);
-    (void)hipStreamDestroy(c->shadow_stream);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->shadow_stream) (void)hipStreamDestroy(c->shadow_stream);
     delete c;
 }
 
@@ -532,8 +546,9 @@ int fovpt_set_scene(fovpt_ctx* c, const fovpt_mesh_desc* meshes, int num_meshes,
     HIPCHK(c, c->meshes.reserve(md.size() * sizeof(MeshDev)));
     HIPCHK(c, hipMemcpy(c->meshes.p, md.data(), md.size() * sizeof(MeshDev), hipMemcpyHostToDevice));
 
-    hipEvent_t e0, e1;
-    HIPCHK(c, hipEventCreate(&e0)); HIPCHK(c, hipEventCreate(&e1));
+    struct Ev { hipEvent_t e = nullptr; ~Ev() { if (e) (void)hipEventDestroy(e); } } ev0, ev1;    // destroyed on every return path
+    HIPCHK(c, hipEventCreate(&ev0.e)); HIPCHK(c, hipEventCreate(&ev1.e));
+    const hipEvent_t e0 = ev0.e, e1 = ev1.e;
     HIPCHK(c, hipEventRecord(e0, c->stream));
     BvhBuildResult br;
     memset(&br, 0, sizeof(br));
@@ -545,7 +560,6 @@ int fovpt_set_scene(fovpt_ctx* c, const fovpt_mesh_desc* meshes, int num_meshes,
     (void)hipEventSynchronize(e1);
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (be != hipSuccess) return fail(c, FOVPT_E_DEVICE, "LBVH build: %s", errbuf);
     if (3 * br.max_depth + 1 > FOVPT_STACK) {       // a wide node leaves at most 3 entries behind
         (void)hipFree(br.nodes); (void)hipFree(br.tris);
@@ -712,7 +726,7 @@ int fovpt_launch(fovpt_ctx* c, const fovpt_launch_params* lp, uint32_t width, ui
     if (!c || !lp) return FOVPT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     PassDev P = pass_from_lp(lp, width, height);
-    return run_passes(c, lp, &P, 1);
+    return run_passes(c, lp, &P, 1, 0);
 }
 
 int fovpt_render(fovpt_ctx* c, fovpt_launch_params* lp)
@@ -736,7 +750,7 @@ int fovpt_render(fovpt_ctx* c, fovpt_launch_params* lp)
         L.viewportSize.x = L.frame.size.x; L.viewportSize.y = L.frame.size.y;
         const uint32_t temp_frame = L.frame.subframe_index;
         P[0] = pass_from_lp(&L, (uint32_t)L.frame.size.x, (uint32_t)L.frame.size.y);
-        rc = run_passes(c, &L, P, 1);
+        rc = run_passes(c, &L, P, 1, 1);
         L.frame.subframe_index = temp_frame;
         L.frame.subframe_index++;
         return rc;
@@ -773,7 +787,7 @@ int fovpt_render(fovpt_ctx* c, fovpt_launch_params* lp)
     L.frame.offset.y = L.frame.c.y - (uint32_t)(inner_radius + 1);
     L.frame.redraw = 1;
     P[2] = pass_from_lp(&L, (uint32_t)(L.frame.r_outer * 2), (uint32_t)(L.frame.r_outer * 2));
-    rc = run_passes(c, &L, P, 3);
+    rc = run_passes(c, &L, P, 3, 1);
     L.frame.subframe_index = temp_frame;
     L.frame.subframe_index++;
     return rc;
@@ -907,8 +921,10 @@ int fovpt_debug_math(fovpt_ctx* c, int op, const float* a, const float* b, float
     if (!c || !a || !out) return FOVPT_E_INVALID;
     if (n == 0) return FOVPT_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    float *da = nullptr, *db = nullptr, *dout = nullptr;
-    HIPCHK(c, hipMalloc(&da, n * 4)); HIPCHK(c, hipMalloc(&db, n * 4)); HIPCHK(c, hipMalloc(&dout, n * 4));
+    DevBuf ba, bb, bo;
+    struct Rel { DevBuf &a, &b, &o; ~Rel() { a.release(); b.release(); o.release(); } } rel = {ba, bb, bo};
+    HIPCHK(c, ba.reserve(n * 4)); HIPCHK(c, bb.reserve(n * 4)); HIPCHK(c, bo.reserve(n * 4));
+    float *da = (float*)ba.p, *db = (float*)bb.p, *dout = (float*)bo.p;
     HIPCHK(c, hipMemcpy(da, a, n * 4, hipMemcpyHostToDevice));
     if (b) HIPCHK(c, hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice));
     else HIPCHK(c, hipMemset(db, 0, n * 4));
@@ -916,7 +932,6 @@ int fovpt_debug_math(fovpt_ctx* c, int op, const float* a, const float* b, float
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
     HIPCHK(c, hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
     return FOVPT_OK;
 }
 

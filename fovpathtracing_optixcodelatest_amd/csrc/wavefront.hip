@@ -1337,8 +1337,8 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_resolve(const FrameDev fd, Path
             if (fd.g_color) fd.g_color[image_index] = fovpt_float4{a.x, a.y, a.z, 1.0f};
             if (fd.g_albedo) fd.g_albedo[image_index] = fovpt_float4{ga.x, ga.y, ga.z, 1.0f};
         }
-    } else if (state == 2 || (fd.world > 1 && fd.rank != 0 && !fd.chunked)) {
-        // another rank's pixel (or nobody's, on a rank other than 0): zero keeps the sum-gather exact
+    } else if (state == 2 || fd.zero_holes) {
+        // another rank's pixel (or, for a whole frame on a rank other than 0, nobody's): zero keeps the sum-gather exact
         fd.accum[image_index] = fovpt_float4{0.f, 0.f, 0.f, 0.f};
         fd.frame[image_index] = 0u;
     }

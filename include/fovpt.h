@@ -223,7 +223,12 @@ int fovpt_get_config(const fovpt_ctx* ctx, fovpt_config* out);
 int fovpt_set_config(fovpt_ctx* ctx, const fovpt_config* cfg);
 
 /* One optixLaunch of the raygen program over a width x height grid with the given
- * parameters (SimplePathtracer.cpp:148-157).  Asynchronous on fovpt_stream().     */
+ * parameters (SimplePathtracer.cpp:148-157).  Asynchronous on fovpt_stream().
+ * With world > 1: a pixel whose last writer in THIS launch is another rank's launch index is
+ * written as zero, a pixel this launch does not write is left untouched on every rank -- so a
+ * frame composed of several launches (P, M, F) sums over the ranks to the single-GPU frame,
+ * provided the ranks other than 0 start the frame from a cleared target (fovpt_render does
+ * that clearing itself).                                                            */
 int fovpt_launch(fovpt_ctx* ctx, const fovpt_launch_params* lp, uint32_t width, uint32_t height);
 
 /* SampleRenderer::render() (SimplePathtracer.cpp:77-214): fills in the per-pass

@@ -748,6 +748,14 @@ struct Opts {
 struct Counters {
     std::atomic<uint64_t> radiance_rays{0}, shadow_rays{0}, paths{0};
 };
+// Rays the LIBRARY traces for the same frame.  The reference (and this restatement) trace two kinds of rays whose
+// results cannot reach the image; libfovpt skips them and tests assert that its device counters
+// equal these numbers exactly:
+//   (i)  the segment at depth == max_depth, discarded by the break at deviceProgram.cu:515 -- unless the scene holds a
+//        shadow catcher (then :689 makes its hit matter) -- and with it the shadow ray of its hit;
+//   (ii) the shadow ray of a hit whose prd.radiance / prd.alpha come out bit-identical whether it is occluded or not,
+//        or (not on a catcher) whose radiance is dropped because BSDFSample returned pdf <= 0 (:708-711 + :515).
+std::atomic<uint64_t> g_lib_radiance{0}, g_lib_shadow{0};
 
 struct Ctx {
     const Scene* S;
@@ -761,14 +769,16 @@ struct Ctx {
 // deviceProgram.cu:303-344 (SampleLights) and :347-387 (SampleShadow, want_occluded = true)
 f3 SampleLightsOrShadow(const Ctx& C, const Material& material, f3 albedo, float etaI, float etaO,
                         const f3& surfacePos, const f3& surfaceNormal, const f3& wo, Random& rand,
-                        bool want_occluded, uint64_t& nshadow)
+                        bool want_occluded, uint64_t& nshadow, f3* sum_if_taken = nullptr)
 {
     f3 sum = mk3(0.0f);
     f3 skyColor; float skyPdf; f3 wi;
     ProbeSample(C.probe, wi, skyColor, skyPdf, rand);
     nshadow++;
     const bool occluded = trace_occluded(*C.S, surfacePos, wi, kTmin, kTmax, C.opt.brute);
-    if (occluded == want_occluded) {
+    // the branch below is a pure function of the hit and wi (no random numbers): evaluated once, used if taken
+    f3 taken = mk3(0.0f);
+    {
         float bsdfPdf = BSDFPdf(material, etaI, etaO, surfaceNormal, wo, wi);
         f3 f = BSDFEval(material, albedo, etaI, etaO, surfaceNormal, wo, wi);
         if (bsdfPdf > 0.0f) {
@@ -778,10 +788,12 @@ f3 SampleLightsOrShadow(const Ctx& C, const Material& material, f3 albedo, float
             float weight = csky * skyPdf / (cbsdf * bsdfPdf + csky * skyPdf);
             if (weight > 0.0f) {
                 f3 val = weight * skyColor * f * fabsf(dot(wi, surfaceNormal)) / skyPdf * (1.0f / 1.f);
-                sum += val;
+                taken += val;
             }
         }
     }
+    if (occluded == want_occluded) sum = taken;
+    if (sum_if_taken) *sum_if_taken = taken;
     return sum;
 }
 
@@ -830,13 +842,24 @@ void traceRadiance(const Ctx& C, const f3& ray_origin, const f3& ray_dir, Radian
         outEta = 1.0f;
         outAbsorption = mk3(0.0f);
     }
-    if ((mat.flags & FOVPT_MATERIAL_FLAG_SHADOW_CATCHER) == 0) {    // :686-694
-        f3 lightSample = SampleLightsOrShadow(C, mat, prd->albedo, prd->rayEta, outEta, P, N, -ray_dir, prd->rand, false, nshadow);
+    const bool catcher = (mat.flags & FOVPT_MATERIAL_FLAG_SHADOW_CATCHER) != 0;
+    const bool lib_shades = prd->depth < C.opt.max_depth;           // the library does not shade the discarded segment's hit
+    f3 sum_taken;                                                   // what SampleLights/SampleShadow returns when its visibility test passes
+    if (!catcher) {                                                 // :686-694
+        f3 lightSample = SampleLightsOrShadow(C, mat, prd->albedo, prd->rayEta, outEta, P, N, -ray_dir, prd->rand, false, nshadow, &sum_taken);
         prd->radiance += prd->pathThroughput * lightSample;
         prd->alpha = mk3(1.0f);
     } else {
-        f3 shadowSample = SampleLightsOrShadow(C, mat, prd->albedo, prd->rayEta, outEta, P, N, -ray_dir, prd->rand, true, nshadow);
+        f3 shadowSample = SampleLightsOrShadow(C, mat, prd->albedo, prd->rayEta, outEta, P, N, -ray_dir, prd->rand, true, nshadow, &sum_taken);
         prd->alpha += prd->pathThroughput * shadowSample;
+    }
+    // does the outcome of the occlusion test change a single bit?  (radiance / alpha were zero before this hit)
+    bool shadow_matters;
+    {
+        const bool primary = (prd->stateFlags & RAY_STATE_FLAGS_SECONDARY_RAY) == 0;
+        f3 a = mk3(0.f) + prd->pathThroughput * sum_taken, b = mk3(0.f) + prd->pathThroughput * mk3(0.0f);
+        if (!catcher && primary) { a += mk3(mat.emission); b += mk3(mat.emission); }
+        shadow_matters = !(a.x == b.x && a.y == b.y && a.z == b.z);
     }
     if ((prd->stateFlags & RAY_STATE_FLAGS_SECONDARY_RAY) == 0) prd->radiance += mk3(mat.emission);   // :696-698
 
@@ -844,6 +867,7 @@ void traceRadiance(const Ctx& C, const f3& ray_origin, const f3& ray_dir, Radian
     BasisFromVector(N, &u, &v);
     f3 bsdfDir; BSDFType bsdfType;
     BSDFSample(mat, prd->rayEta, outEta, u, v, N, -ray_dir, bsdfDir, prd->bsdfPdf, bsdfType, prd->rand);   // :706
+    if (lib_shades && shadow_matters && (catcher || prd->bsdfPdf > 0.0f)) g_lib_shadow++;
     if (prd->bsdfPdf <= 0.0f) {                                     // :708-711
         prd->stateFlags |= RAY_STATE_FLAGS_DONE;
         return;
@@ -905,7 +929,7 @@ void raygen(const Ctx& C, uint32_t lx, uint32_t ly)
     f3 albedo = mk3(0.f);
     f3 alpha = mk3(0.f);
     f3 backplate = mk3(0.f);
-    uint64_t nrad = 0, nshadow = 0, npaths = 0;
+    uint64_t nrad = 0, nshadow = 0, npaths = 0, nlib = 0;
     do {
         f3 directLight = mk3(0.0f), indirectLight = mk3(0.0f);
         RadiancePRD prd;
@@ -930,6 +954,7 @@ void raygen(const Ctx& C, uint32_t lx, uint32_t ly)
         npaths++;
         for (;;) {
             prd.radiance = mk3(0.f);
+            if (prd.depth < C.opt.max_depth || C.S->any_catcher) nlib++;            // (the library skips the discarded segment)
             traceRadiance(C, ray_origin, ray_direction, &prd, nrad, nshadow);       // :501
             if (prd.depth == 0.f) {                                                 // :509-512
                 normal += prd.normal;
@@ -946,6 +971,7 @@ void raygen(const Ctx& C, uint32_t lx, uint32_t ly)
         alpha += prd.alpha;
     } while (--i);
     C.cnt->radiance_rays += nrad; C.cnt->shadow_rays += nshadow; C.cnt->paths += npaths;
+    g_lib_radiance += nlib;
     normal /= static_cast<float>(samples_per_launch);                               // :541-542
     albedo /= static_cast<float>(samples_per_launch);
     alpha /= static_cast<float>(samples_per_launch);                                // :543
@@ -1157,6 +1183,13 @@ int orc_render(void* scene, fovpt_launch_params* lp, const fovpt_config* cfg, in
     L.frame.subframe_index = (uint32_t)temp_frame;
     L.frame.subframe_index++;
     return rc;
+}
+
+/* rays libfovpt traces for the frames rendered since the last reset (see g_lib_radiance above) */
+void orc_lib_counts(uint64_t* out2, int reset)
+{
+    if (out2) { out2[0] = g_lib_radiance; out2[1] = g_lib_shadow; }
+    if (reset) { g_lib_radiance = 0; g_lib_shadow = 0; }
 }
 
 /* ---- unit-level entry points --------------------------------------------------------- */

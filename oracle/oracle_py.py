@@ -45,6 +45,7 @@ def lib():
         L.orc_tea4.argtypes = [C.c_uint32, C.c_uint32]
         L.orc_trace.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_math.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_lib_counts.argtypes = [C.c_void_p, C.c_int]
         L.orc_camera_uvw.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
@@ -143,25 +144,43 @@ class OracleFrame:
         self.lp = lp
 
 
+class Counts(tuple):
+    """(radiance_rays, shadow_rays, paths) as the REFERENCE traces them, plus .lib_radiance / .lib_shadow: the rays
+    libfovpt traces for the same frame (it skips the reference's discarded last segment and shadow rays that cannot
+    change a bit of the image; fovpt_oracle.cpp, g_lib_radiance).  The library's device counters must equal them."""
+    lib_radiance = 0
+    lib_shadow = 0
+
+
+def _counts(cnt):
+    lc = np.zeros(2, np.uint64)
+    lib().orc_lib_counts(_p(lc), 1)
+    c = Counts(int(x) for x in cnt)
+    c.lib_radiance, c.lib_shadow = int(lc[0]), int(lc[1])
+    return c
+
+
 def render(scene: OracleScene, frame: OracleFrame, cfg: abi.Config, brute=False, nthreads=None):
-    """SampleRenderer::render() on the CPU.  Returns (radiance_rays, shadow_rays, paths)."""
+    """SampleRenderer::render() on the CPU.  Returns Counts(radiance_rays, shadow_rays, paths)."""
     if nthreads is None:
         nthreads = os.cpu_count() or 1
     cnt = np.zeros(3, np.uint64)
+    lib().orc_lib_counts(None, 1)
     rc = lib().orc_render(scene._h, C.byref(frame.lp), C.byref(cfg), int(brute), int(nthreads), _p(cnt))
     if rc != 0:
         raise RuntimeError("orc_render failed: %d" % rc)
-    return tuple(int(x) for x in cnt)
+    return _counts(cnt)
 
 
 def launch(scene: OracleScene, frame: OracleFrame, width, height, max_depth=4, accumulate=0, brute=False, nthreads=None):
     if nthreads is None:
         nthreads = os.cpu_count() or 1
     cnt = np.zeros(3, np.uint64)
+    lib().orc_lib_counts(None, 1)
     rc = lib().orc_launch(scene._h, C.byref(frame.lp), width, height, max_depth, accumulate, int(brute), int(nthreads), _p(cnt))
     if rc != 0:
         raise RuntimeError("orc_launch failed: %d" % rc)
-    return tuple(int(x) for x in cnt)
+    return _counts(cnt)
 
 
 def math_op(op, a, b=None):

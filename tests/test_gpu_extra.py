@@ -255,6 +255,7 @@ def test_full_size_benchmark_configs_against_oracle(oracle, name):
     assert bits == 0 and px == 0, (l2, bits, px)
     assert st.paths == cnt[2]
     assert st.radiance_rays <= cnt[0] and st.shadow_rays <= cnt[1]
+    assert (st.radiance_rays, st.shadow_rays) == (cnt.lib_radiance, cnt.lib_shadow)      # exact ray accounting
     assert np.isfinite(ga).all()
     # the three rings do not tile the frame exactly: a 4x4 periphery block whose top-left corner is inside
     # r_outer is skipped although its far pixels lie beyond the middle ring (reference behaviour, kept)
@@ -280,6 +281,7 @@ def test_bistro_class_scene_full_size_against_oracle(oracle):
     l2, bits, px = compare_frames(ga, gf, F.accum, F.frame)
     assert l2 <= 1e-4 and bits == 0 and px == 0, (l2, bits, px)
     assert st.paths == cnt[2] == 1726659          # paths per frame of C4
+    assert (st.radiance_rays, st.shadow_rays) == (cnt.lib_radiance, cnt.lib_shadow)
 
 
 def test_c5_stereo_bistro_class_full_size_against_oracle(oracle):
@@ -312,6 +314,7 @@ def test_c5_stereo_bistro_class_full_size_against_oracle(oracle):
         l2, bits, px = compare_frames(ga, gf, F.accum, F.frame)
         assert l2 <= 1e-4 and bits == 0 and px == 0, (side, l2, bits, px)
         assert st.paths == cnt[2] == 3654059, (st.paths, cnt[2])
+        assert (st.radiance_rays, st.shadow_rays) == (cnt.lib_radiance, cnt.lib_shadow)
         assert np.isfinite(ga).all()
         total_rays += st.radiance_rays + st.shadow_rays
     assert total_rays > 2 * 3654059
@@ -332,6 +335,7 @@ def test_c1_cornell_full_size_against_oracle(oracle):
     l2, bits, px = compare_frames(ga, gf, F.accum, F.frame)
     assert l2 <= 1e-4 and bits == 0 and px == 0, (l2, bits, px)
     assert st.paths == cnt[2] == 512 * 512 * 4
+    assert (st.radiance_rays, st.shadow_rays) == (cnt.lib_radiance, cnt.lib_shadow)
 
 
 def test_obj_loaded_textured_scene(oracle, tmp_path):
@@ -539,10 +543,14 @@ def test_random_configurations(oracle, seed):
     sub = int(rng.integers(0, 4))
     r = make_gpu(model, probe, cam, (w, h), cfg, gaze=gaze, subframe_index=sub)
     S, F = make_oracle(oracle, model, probe, cam, (w, h), gaze=gaze, subframe_index=sub)
+    want_rays = [0, 0, 0]
     for _ in range(2):                                   # two frames: subframe_index advances, accumulate blends
         r.render()
-        oracle.render(S, F, cfg)
+        cnt = oracle.render(S, F, cfg)
+        want_rays = [want_rays[0] + cnt.lib_radiance, want_rays[1] + cnt.lib_shadow, want_rays[2] + cnt[2]]
         assert _bits_equal(r.downloadAccum(), F.accum) and np.array_equal(r.downloadPixels(), F.frame), (w, h, gaze, sub)
+    st = r.stats()
+    assert [st.radiance_rays, st.shadow_rays, st.paths] == want_rays          # exact ray accounting
     r.close()
 
 

@@ -178,9 +178,14 @@ def test_bench_two_rank_rehearsal_gathers_the_full_frame():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import socket
     env = dict(os.environ, FOVPT_BENCH_REHEARSAL="1", FOVPT_BENCH_CHECK="1", MASTER_ADDR="127.0.0.1")
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))                               # a free port, not a fixed one (no EADDRINUSE on a busy box)
+    port = sock.getsockname()[1]
+    sock.close()
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(root, "bench.py"),
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
                           "--gpus", "2", "--steps", "6", "--warmup", "2"], capture_output=True, text=True, env=env, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
     line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
@@ -217,6 +222,85 @@ def test_chunked_jobs_for_large_launches(oracle, monkeypatch, uniform):
         total += rr.downloadPixels()
         rr.close()
     assert np.array_equal(total.astype(np.uint32), F.frame)
+
+
+@pytest.mark.parametrize("budget", [None, "4000"])
+def test_accumulating_tile_shards_sum_to_the_oracle(oracle, monkeypatch, budget):
+    """accumulate = 1 + world > 1, unchunked and cut into chunks by a small slot budget: every rank blends
+    its owned periphery pixels with ITS history of them (static gaze: the owner of a pixel does not change), foreign
+    pixels and -- on ranks other than 0 -- holes stay zero, so the shards add up to the oracle's frame after each of
+    several progressive frames."""
+    if budget:
+        monkeypatch.setenv("FOVPT_SLOT_BUDGET", budget)
+    size = (160, 96)
+    model, probe = scenes.atrium(5000), scenes.sky_probe()
+    cfg = cfg_foveated(10, 30, (1, 2, 4))
+    cfg.accumulate = 1
+    world = 3
+    ranks = []
+    for rank in range(world):
+        c = cfg.copy()
+        c.rank, c.world = rank, world
+        ranks.append(make_gpu(model, probe, scenes.ATRIUM_CAMERA, size, c))
+    S, F = make_oracle(oracle, model, probe, scenes.ATRIUM_CAMERA, size)
+    for k in range(3):
+        oracle.render(S, F, cfg)
+        sa = np.zeros_like(F.accum)
+        sf = np.zeros(F.frame.shape, np.uint64)
+        for r in ranks:
+            r.render()
+            sa += r.downloadAccum()
+            sf += r.downloadPixels()
+        assert _eq(sa, F.accum), k
+        assert np.array_equal(sf.astype(np.uint32), F.frame), k
+    for r in ranks:
+        r.close()
+
+
+def test_three_separate_launches_per_frame_with_tile_shards():
+    """A caller that issues the P, M and F passes as three fovpt_launch calls (= three optixLaunch, SimplePathtracer.cpp:
+    148-209) with world > 1: a later launch must not wipe what this rank wrote in an earlier one; the
+    per-rank frames still sum to the single-GPU frame."""
+    size = (192, 108)
+    W, H = size
+    model, probe = scenes.atrium(8000), scenes.ambient_probe(96, 54, 2.5)
+    ri, ro = 15, 48
+    cfg = cfg_foveated(ri, ro, (1, 2, 8))
+    full = make_gpu(model, probe, scenes.ATRIUM_CAMERA, size, cfg)
+    full.render()
+    fa, ff = full.downloadAccum(), full.downloadPixels()
+    full.close()
+
+    def three_launches(r):
+        lp, f = r.launchParams, r.launchParams.frame
+        f.subframe_index = 0
+        f.factor.x, f.factor.y, f.factor.z, f.fillSize = 4, 4, 1, 4
+        f.r_inner, f.r_outer, f.offset.x, f.offset.y, f.redraw = float(ro), 1e9, 0, 0, 0
+        lp.samples_per_launch = 1
+        r.launch(W // 4, H // 4)
+        f.factor.x, f.factor.y, f.fillSize = 2, 2, 2
+        f.r_inner, f.r_outer, f.offset.x, f.offset.y, f.redraw = float(ri), float(ro + 2), W // 2 - (ro + 2), H // 2 - (ro + 2), 1
+        lp.samples_per_launch = 2
+        r.launch(ro + 2, ro + 2)
+        f.factor.x, f.factor.y, f.fillSize = 1, 1, 1
+        f.r_inner, f.r_outer, f.offset.x, f.offset.y = 0.0, float(ri + 1), W // 2 - (ri + 1), H // 2 - (ri + 1)
+        lp.samples_per_launch = 8
+        r.launch(2 * (ri + 1), 2 * (ri + 1))
+        r.synchronize()
+
+    for world in (1, 2, 4):
+        sa = np.zeros_like(fa)
+        sf = np.zeros(ff.shape, np.uint64)
+        for rank in range(world):
+            c = cfg.copy()
+            c.rank, c.world = rank, world
+            r = make_gpu(model, probe, scenes.ATRIUM_CAMERA, size, c)
+            three_launches(r)
+            sa += r.downloadAccum()
+            sf += r.downloadPixels()
+            r.close()
+        assert _eq(sa, fa), world
+        assert np.array_equal(sf.astype(np.uint32), ff), world
 
 
 def test_stereo_asymmetric_frusta(oracle):

@@ -80,8 +80,10 @@ def test_cornell_uniform_bit_exact(oracle):
     assert l2 <= TOL_REL_L2, l2
     assert bits == 0 and px == 0, (l2, bits, px)
     assert st.paths == cnt[2]
-    # the library skips the reference's discarded last segment and shadow rays with no effect
+    # the library skips the reference's discarded last segment and shadow rays that cannot change a bit; the oracle
+    # counts by the same two rules (Counts.lib_*) and the device counters must agree EXACTLY
     assert 0 < st.radiance_rays <= cnt[0] and 0 < st.shadow_rays <= cnt[1]
+    assert (st.radiance_rays, st.shadow_rays) == (cnt.lib_radiance, cnt.lib_shadow)
 
 
 def test_cornell_foveated_three_pass(oracle):
@@ -90,6 +92,7 @@ def test_cornell_foveated_three_pass(oracle):
     l2, bits, px = compare_frames(ga, gf, oa, of)
     assert bits == 0 and px == 0, (l2, bits, px)
     assert st.paths == cnt[2]
+    assert (st.radiance_rays, st.shadow_rays) == (cnt.lib_radiance, cnt.lib_shadow)
 
 
 def test_atrium_foveated_textured(oracle):
@@ -99,6 +102,7 @@ def test_atrium_foveated_textured(oracle):
     l2, bits, px = compare_frames(ga, gf, oa, of)
     assert bits == 0 and px == 0, (l2, bits, px)
     assert st.paths == cnt[2]
+    assert (st.radiance_rays, st.shadow_rays) == (cnt.lib_radiance, cnt.lib_shadow)
     assert np.isfinite(ga).all()
 
 
