@@ -40,7 +40,7 @@ struct EventPair { hipEvent_t a, b; int kind; };   // kind: 0 gen, 1 trace, 2 sh
 #define FOVPT_NSQ 4
 
 struct StateSet {
-    DevBuf s_thr, s_rng, s_hit, s_rad, s_alpha, s_backplate, s_guide_n, s_guide_a;
+    DevBuf s_thr, s_rng, s_hit, s_rad, s_alpha, s_backplate, s_guide_n, s_guide_a, s_trace;
     DevBuf q_o[2], q_d[2], counters;       // q_*: the two radiance-ray queues (ping-pong)
     DevBuf sq_o[FOVPT_NSQ], sq_d[FOVPT_NSQ], sq_vis[FOVPT_NSQ], sq_occ[FOVPT_NSQ];   // shadow queues, one per bounce in flight
     hipEvent_t ev_shade[FOVPT_MAX_ITERS + 1] = {};
@@ -49,7 +49,7 @@ struct StateSet {
     bool used = false;
     std::vector<DevBuf*> all()
     {
-        std::vector<DevBuf*> v = {&q_o[0], &q_d[0], &q_o[1], &q_d[1], &s_thr, &s_rng, &s_hit, &s_rad, &s_alpha, &s_backplate, &s_guide_n, &s_guide_a, &counters};
+        std::vector<DevBuf*> v = {&q_o[0], &q_d[0], &q_o[1], &q_d[1], &s_thr, &s_rng, &s_hit, &s_rad, &s_alpha, &s_backplate, &s_guide_n, &s_guide_a, &s_trace, &counters};
         for (int k = 0; k < FOVPT_NSQ; k++) { v.push_back(&sq_o[k]); v.push_back(&sq_d[k]); v.push_back(&sq_vis[k]); v.push_back(&sq_occ[k]); }
         return v;
     }
@@ -83,7 +83,7 @@ struct fovpt_ctx {
     // rays and its resolve, on the shadow stream) runs beside the head of job k+1 (generate, camera rays)
     StateSet set[2];
     unsigned jobs = 0;                     // jobs issued so far; job j uses set[j & 1]
-    int grid = 2048, grid_shadow = 1024;
+    int grid = 2048, grid_shadow = 1024, grid_shade = 1024;
     uint64_t slot_budget = 64ull << 20;    // sample slots per wavefront job (~330 B of state and queues each, two sets)
     // stats
     fovpt_stats stats;
@@ -183,6 +183,9 @@ int ensure_state(fovpt_ctx* c, StateSet& S, size_t slots, size_t launches)
     const size_t v = 16;
     HIPCHK(c, S.s_thr.reserve(slots * v)); HIPCHK(c, S.s_rng.reserve(slots * v));
     HIPCHK(c, S.s_hit.reserve((size_t)shard_capacity(slots) * FOVPT_SHARDS * v));      // indexed like the ray queues
+#if FOVPT_V_STEPSTAT
+    HIPCHK(c, S.s_trace.reserve((size_t)shard_capacity(slots) * FOVPT_SHARDS * v));
+#endif
     HIPCHK(c, S.s_alpha.reserve(slots * v));
     HIPCHK(c, S.s_rad.reserve(slots * v * (size_t)c->cfg.max_depth));
     HIPCHK(c, S.s_backplate.reserve(launches * v));
@@ -337,6 +340,9 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     ps.alpha = (float4*)S.s_alpha.p; ps.backplate = (float4*)S.s_backplate.p;
     ps.guide_n = c->cfg.write_guides ? (float4*)S.s_guide_n.p : nullptr;
     ps.guide_a = c->cfg.write_guides ? (float4*)S.s_guide_a.p : nullptr;
+#if FOVPT_V_STEPSTAT
+    ps.trace = (uint4*)S.s_trace.p;
+#endif
     ShadowQueue sq[FOVPT_NSQ];
     for (int k = 0; k < FOVPT_NSQ; k++) {
         sq[k].o = (float4*)S.sq_o[k].p; sq[k].d = (float4*)S.sq_d[k].p;
@@ -373,7 +379,7 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
         if (it >= nsq) HIPCHK(c, hipStreamWaitEvent(st, S.ev_shadow[it - nsq], 0));
         // the events ride on the kernels' own completion signals (hipExtLaunchKernel): a separate
         // hipEventRecord would put a marker packet between shade(it) and closest(it+1), ~6 us on the critical path
-        { Timed t(c, 2); fovpt_launch_shade(st, fd, sc, ps, qa, qb, sq[it % nsq], cap, cnt, it, grid, S.ev_shade[it]); }
+        { Timed t(c, 2); fovpt_launch_shade(st, fd, sc, ps, qa, qb, sq[it % nsq], cap, cnt, it, c->grid_shade, S.ev_shade[it]); }
         HIPCHK(c, hipStreamWaitEvent(ss, S.ev_shade[it], 0));
         { Timed t(c, 3, ss); fovpt_launch_traverse(ss, sc, ps, qb, sq[it % nsq], cap, cnt, -1, it, c->grid_shadow, S.ev_shadow[it]); }
         if (it + 1 < iters) { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qb, sq[0], cap, cnt, it + 1, -1, grid); }
@@ -424,6 +430,11 @@ int fovpt_create(fovpt_ctx** out, int device)
     if (const char* g = getenv("FOVPT_GRID")) { const int v = atoi(g); if (v > 0 && v <= 16) c->grid = c->num_cus * v; }                 // tuning: blocks per CU
     if (const char* g = getenv("FOVPT_GRID_SHADOW")) { const int v = atoi(g); if (v > 0 && v <= 16) c->grid_shadow = c->num_cus * v; }   // tuning: blocks per CU
     c->grid = (c->grid + FOVPT_SHARDS - 1) / FOVPT_SHARDS * FOVPT_SHARDS;      // shard_capacity() relies on it
+    // the shading kernel holds 4 waves per SIMD (104 VGPRs) = 4 blocks per CU; twice the resident number of blocks is
+    // measured best (blocks per CU 2 / 3 / 4 / 6 / 8: shading 0.307 / 0.274 / 0.261 / 0.263 / 0.244 ms per C3 frame)
+    c->grid_shade = c->grid;
+    if (const char* g = getenv("FOVPT_GRID_SHADE")) { const int v = atoi(g); if (v > 0 && v <= 16) c->grid_shade = c->num_cus * v; }     // tuning: blocks per CU
+    c->grid_shade = (c->grid_shade + FOVPT_SHARDS - 1) / FOVPT_SHARDS * FOVPT_SHARDS;
     if (const char* sb = getenv("FOVPT_SLOT_BUDGET")) { const long long v = atoll(sb); if (v > 0) c->slot_budget = (uint64_t)v; }   // tests: force chunking
     // the main chain is the critical path: give it the higher priority so occlusion waves only fill gaps
     int prio_lo = 0, prio_hi = 0;
@@ -909,7 +920,7 @@ int fovpt_debug_buffer(fovpt_ctx* c, const char* name, void** ptr, size_t* bytes
     StateSet& S = c->set[(c->jobs + 1u) & 1u];            // the set the most recent job used
     struct { const char* n; DevBuf* b; } tab[] = {
         {"sq_o", &S.sq_o[0]}, {"sq_d", &S.sq_d[0]}, {"sq_vis", &S.sq_vis[0]}, {"sq_occ", &S.sq_occ[0]}, {"counters", &S.counters},
-        {"hit", &S.s_hit}, {"queue_a_o", &S.q_o[0]}, {"queue_a_d", &S.q_d[0]}, {"queue_b_o", &S.q_o[1]}, {"queue_b_d", &S.q_d[1]},
+        {"hit", &S.s_hit}, {"trace", &S.s_trace}, {"queue_a_o", &S.q_o[0]}, {"queue_a_d", &S.q_d[0]}, {"queue_b_o", &S.q_o[1]}, {"queue_b_d", &S.q_d[1]},
     };
     for (auto& t : tab)
         if (strcmp(t.n, name) == 0) { *ptr = t.b->p; *bytes = t.b->bytes; return FOVPT_OK; }

@@ -129,6 +129,9 @@ struct PathState {
     float4* guide_n;    // write_guides: prd.normal of the primary hit (deviceProgram.cu:509-512), else null
     float4* guide_a;    // write_guides: prd.albedo of the primary hit
     float4* backplate;  // per launch record: backplate of the last sample (deviceProgram.cu:495)
+#if FOVPT_V_STEPSTAT
+    uint4* trace;       // diagnostics: node steps of each of the ray's first 16 node phases, one byte each (tools/raysim.py)
+#endif
 };
 
 // Shadow (occlusion) ray queue, indexed by queue position.

@@ -675,6 +675,8 @@ struct QuadTrav {                                   // state of one ray's traver
     float bt, bu, bv; uint32_t bpos, bprim;         // best hit among the triangles THIS lane tested
 #if FOVPT_V_STEPSTAT
     uint32_t steps;                                 // diagnostics: node steps | leaf steps << 16 of this ray
+    unsigned long long tr_lo, tr_hi;                // node steps of the first 15 node phases, one byte each (tools/raysim.py)
+    uint32_t n0;                                    // node steps in which no child was hit (top byte of the trace)
 #endif
     // Row 0 holds the end marker, so "pop" needs no emptiness test; all row arithmetic stays in bytes.
     __device__ inline void start(int* stack, const QuadLane& q)
@@ -710,6 +712,9 @@ __device__ inline void node_step(const SceneView& sc, const RayT& r, const QuadL
     const uint32_t m4 = (uint32_t)(__builtin_amdgcn_ballot_w64(h) >> q.qshift) & 15u;
     int Hm1;                                    // H - 1 in one instruction (the compiler splits popcount - 1)
     asm("v_bcnt_u32_b32 %0, %1, -1" : "=v"(Hm1) : "v"(m4));
+#if FOVPT_V_STEPSTAT
+    if (m4 == 0u) T.n0++;
+#endif
     // Every lane stores its child: the H hits land on rows top .. top+H-1 (the one to visit next
     // last), the misses on the free rows above them -- no branch, no select on the address.
     int row;                                    // in bytes, relative to top
@@ -809,14 +814,20 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
 {
     T.start(stack, q);
 #if FOVPT_V_STEPSTAT
+    // (no arrays with a run-time index here: a diagnostic build whose traversal kernel used scratch memory faulted with
+    // HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on the closest-hit launch; the product kernels use none)
     uint32_t nn = 0, nl = 0;
+    T.tr_lo = T.tr_hi = 0ull; T.n0 = 0u;
     for (;;) {
-        while (T.cur >= 0) { STEPSTAT(diag); node_step<false>(sc, r, q, T); nn++; }
+        uint32_t ph = 0;
+        while (T.cur >= 0) { STEPSTAT(diag); node_step<false>(sc, r, q, T); nn++; ph++; }
+        { const unsigned long long v = (unsigned long long)min(ph, 255u) << ((nl & 7u) * 8u); if (nl < 8u) T.tr_lo |= v; else if (nl < 15u) T.tr_hi |= v; }
         if (T.cur == TRAV_DONE) break;
         STEPSTAT(diag + 2);
         leaf_step<false>(sc, r, q, T); nl++;
     }
     T.steps = nn | (nl << 16);
+    T.tr_hi |= (unsigned long long)min(T.n0, 255u) << 56;
 #else
     for (;;) {
         while (T.cur >= 0) node_step<false>(sc, r, q, T);
@@ -913,7 +924,10 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
         traverse_quad(sc, r, stack, q, T, cnt->diag[0]);
         store_hit(ps, ph, T);
 #if FOVPT_V_STEPSTAT
-        if (q.j == 0) ((uint32_t*)&queue.d[ph])[3] = T.steps;            // tools/raystat.py
+        if (q.j == 0) {                                                   // tools/raystat.py, raytrace_dump.py
+            ((uint32_t*)&queue.d[ph])[3] = T.steps;
+            ps.trace[ph] = make_uint4((uint32_t)T.tr_lo, (uint32_t)(T.tr_lo >> 32), (uint32_t)T.tr_hi, (uint32_t)(T.tr_hi >> 32));
+        }
 #endif
     }
 }

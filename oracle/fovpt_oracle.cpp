@@ -755,7 +755,7 @@ struct Counters {
 //        shadow catcher (then :689 makes its hit matter) -- and with it the shadow ray of its hit;
 //   (ii) the shadow ray of a hit whose prd.radiance / prd.alpha come out bit-identical whether it is occluded or not,
 //        or (not on a catcher) whose radiance is dropped because BSDFSample returned pdf <= 0 (:708-711 + :515).
-std::atomic<uint64_t> g_lib_radiance{0}, g_lib_shadow{0};
+std::atomic<uint64_t> g_lib_radiance{0}, g_lib_shadow{0}, g_occluded{0};      // g_occluded: diagnostics, occluded shadow rays (all)
 
 struct Ctx {
     const Scene* S;
@@ -776,6 +776,7 @@ f3 SampleLightsOrShadow(const Ctx& C, const Material& material, f3 albedo, float
     ProbeSample(C.probe, wi, skyColor, skyPdf, rand);
     nshadow++;
     const bool occluded = trace_occluded(*C.S, surfacePos, wi, kTmin, kTmax, C.opt.brute);
+    if (occluded) g_occluded++;
     // the branch below is a pure function of the hit and wi (no random numbers): evaluated once, used if taken
     f3 taken = mk3(0.0f);
     {
@@ -1190,6 +1191,12 @@ void orc_lib_counts(uint64_t* out2, int reset)
 {
     if (out2) { out2[0] = g_lib_radiance; out2[1] = g_lib_shadow; }
     if (reset) { g_lib_radiance = 0; g_lib_shadow = 0; }
+}
+uint64_t orc_occluded_count(int reset)
+{
+    const uint64_t v = g_occluded;
+    if (reset) g_occluded = 0;
+    return v;
 }
 
 /* ---- unit-level entry points --------------------------------------------------------- */
