@@ -78,6 +78,10 @@ struct fovpt_ctx {
     // frame buffers (resize)
     DevBuf fb_frame, fb_accum, fb_color, fb_normal, fb_albedo;
     DevBuf accum_before;                   // accumulate mode, chunked launch: the accum buffer as it was before the launch
+    // multi-GPU gather plan (fovpt_gather_plan): pixel indices grouped by owning rank
+    DevBuf plan_owner, plan_blocks, plan_total, plan_base, plan_idx;
+    std::vector<uint32_t> plan_off;        // host copy: rank r owns plan_idx[plan_off[r] .. plan_off[r + 1])
+    std::string plan_key;                  // what the plan was built for
     bool use_accum_before = false;
     // Wavefront state, TWO sets used alternately by consecutive jobs: the tail of job k (its last occlusion
     // rays and its resolve, on the shadow stream) runs beside the head of job k+1 (generate, camera rays)
@@ -132,6 +136,7 @@ struct Timed {
     fovpt_ctx* c; int kind; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
     Timed(fovpt_ctx* c_, int k, hipStream_t s = nullptr) : c(c_), kind(k), st(s ? s : c_->stream)
     {
+        if (c->cfg.profile == 2) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->shadow_stream); }   // the kernel runs alone
         if (c->cfg.profile) {
             a = get_event(c); b = get_event(c);
             if (a && b) (void)hipEventRecord(a, st);
@@ -141,6 +146,7 @@ struct Timed {
     ~Timed()
     {
         if (a && b) { (void)hipEventRecord(b, st); EventPair p = {a, b, kind}; c->pending.push_back(p); }
+        if (c->cfg.profile == 2) (void)hipStreamSynchronize(st);
     }
 };
 
@@ -405,6 +411,57 @@ PassDev pass_from_lp(const fovpt_launch_params* lp, uint32_t gw, uint32_t gh)
     return P;
 }
 
+// The launches of one SampleRenderer::render() call (SimplePathtracer.cpp:77-214): sets the per-pass members of L the
+// way the reference leaves them after its last launch and returns the passes.  (The caller restores subframe_index.)
+int frame_passes(const fovpt_config& cfg, fovpt_launch_params& L, PassDev* P)
+{
+    if (cfg.uniform) {                                                                       // FOV_OFF :85-131
+        L.frame.subframe_index = 0;
+        L.frame.factor.x = L.frame.factor.y = L.frame.factor.z = 1;
+        L.frame.fillSize = 1;
+        L.frame.r_outer = 1000000000;
+        L.frame.r_inner = 0;
+        L.samples_per_launch = (uint32_t)cfg.spp_uniform;
+        L.frame.offset.x = L.frame.offset.y = 0;
+        L.frame.redraw = 0;
+        L.viewportSize.x = L.frame.size.x; L.viewportSize.y = L.frame.size.y;
+        P[0] = pass_from_lp(&L, (uint32_t)L.frame.size.x, (uint32_t)L.frame.size.y);
+        return 1;
+    }
+    const int inner_radius = cfg.r_inner, outer_radius = cfg.r_outer;
+    // periphery :137-157
+    L.frame.factor.x = 4; L.frame.factor.y = 4; L.frame.factor.z = 1;
+    L.frame.fillSize = 4;
+    L.frame.r_outer = 1000000000;
+    L.frame.r_inner = (float)outer_radius;
+    L.samples_per_launch = (uint32_t)cfg.spp_periphery;
+    L.frame.offset.x = L.frame.offset.y = 0;
+    L.frame.redraw = 0;
+    P[0] = pass_from_lp(&L, (uint32_t)(L.frame.size.x / 4), (uint32_t)(L.frame.size.y / 4));
+    // intermediate :160-187
+    L.frame.subframe_index = 0;
+    L.frame.factor.x = 2; L.frame.factor.y = 2; L.frame.factor.z = 1;
+    L.frame.fillSize = 2;
+    L.frame.r_outer = (float)(outer_radius + 2);
+    L.frame.r_inner = (float)inner_radius;
+    L.samples_per_launch = (uint32_t)cfg.spp_middle;
+    L.frame.offset.x = L.frame.c.x - (uint32_t)(outer_radius + 2);
+    L.frame.offset.y = L.frame.c.y - (uint32_t)(outer_radius + 2);
+    L.frame.redraw = 1;
+    P[1] = pass_from_lp(&L, (uint32_t)L.frame.r_outer, (uint32_t)L.frame.r_outer);
+    // fovea :189-209
+    L.frame.factor.x = 1; L.frame.factor.y = 1; L.frame.factor.z = 1;
+    L.frame.fillSize = 1;
+    L.frame.r_outer = (float)(inner_radius + 1);
+    L.frame.r_inner = 0;
+    L.samples_per_launch = (uint32_t)cfg.spp_fovea;
+    L.frame.offset.x = L.frame.c.x - (uint32_t)(inner_radius + 1);
+    L.frame.offset.y = L.frame.c.y - (uint32_t)(inner_radius + 1);
+    L.frame.redraw = 1;
+    P[2] = pass_from_lp(&L, (uint32_t)(L.frame.r_outer * 2), (uint32_t)(L.frame.r_outer * 2));
+    return 3;
+}
+
 }  // namespace
 
 extern "C" {
@@ -471,7 +528,8 @@ void fovpt_destroy(fovpt_ctx* c)
     }
     free_scene(c);
     DevBuf* bufs[] = {&c->tri_tc, &c->meshes, &c->textures, &c->pr_data, &c->pr_pdfx, &c->pr_cdfx, &c->pr_pdfy, &c->pr_cdfy, &c->pr_guidex, &c->pr_guidey,
-                      &c->fb_frame, &c->fb_accum, &c->fb_color, &c->fb_normal, &c->fb_albedo, &c->accum_before};
+                      &c->fb_frame, &c->fb_accum, &c->fb_color, &c->fb_normal, &c->fb_albedo, &c->accum_before,
+                      &c->plan_owner, &c->plan_blocks, &c->plan_total, &c->plan_base, &c->plan_idx};
     for (DevBuf* b : bufs) b->release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->shadow_stream) (void)hipStreamDestroy(c->shadow_stream);
@@ -745,63 +803,87 @@ int fovpt_render(fovpt_ctx* c, fovpt_launch_params* lp)
     if (!c || !lp) return FOVPT_E_INVALID;
     if (lp->frame.size.x == 0) return FOVPT_OK;                                              // :81-82
     HIPCHK(c, hipSetDevice(c->device));
-    fovpt_launch_params& L = *lp;
-    const fovpt_config& cfg = c->cfg;
     PassDev P[3];
-    int rc;
-    if (cfg.uniform) {                                                                       // FOV_OFF :85-131
-        L.frame.subframe_index = 0;
-        L.frame.factor.x = L.frame.factor.y = L.frame.factor.z = 1;
-        L.frame.fillSize = 1;
-        L.frame.r_outer = 1000000000;
-        L.frame.r_inner = 0;
-        L.samples_per_launch = (uint32_t)cfg.spp_uniform;
-        L.frame.offset.x = L.frame.offset.y = 0;
-        L.frame.redraw = 0;
-        L.viewportSize.x = L.frame.size.x; L.viewportSize.y = L.frame.size.y;
-        const uint32_t temp_frame = L.frame.subframe_index;
-        P[0] = pass_from_lp(&L, (uint32_t)L.frame.size.x, (uint32_t)L.frame.size.y);
-        rc = run_passes(c, &L, P, 1, 1);
-        L.frame.subframe_index = temp_frame;
-        L.frame.subframe_index++;
-        return rc;
-    }
-    const int inner_radius = cfg.r_inner, outer_radius = cfg.r_outer;
-    // periphery :137-157
-    L.frame.factor.x = 4; L.frame.factor.y = 4; L.frame.factor.z = 1;
-    L.frame.fillSize = 4;
-    L.frame.r_outer = 1000000000;
-    L.frame.r_inner = (float)outer_radius;
-    L.samples_per_launch = (uint32_t)cfg.spp_periphery;
-    L.frame.offset.x = L.frame.offset.y = 0;
-    L.frame.redraw = 0;
-    P[0] = pass_from_lp(&L, (uint32_t)(L.frame.size.x / 4), (uint32_t)(L.frame.size.y / 4));
-    // intermediate :160-187
-    const uint32_t temp_frame = L.frame.subframe_index;
-    L.frame.subframe_index = 0;
-    L.frame.factor.x = 2; L.frame.factor.y = 2; L.frame.factor.z = 1;
-    L.frame.fillSize = 2;
-    L.frame.r_outer = (float)(outer_radius + 2);
-    L.frame.r_inner = (float)inner_radius;
-    L.samples_per_launch = (uint32_t)cfg.spp_middle;
-    L.frame.offset.x = L.frame.c.x - (uint32_t)(outer_radius + 2);
-    L.frame.offset.y = L.frame.c.y - (uint32_t)(outer_radius + 2);
-    L.frame.redraw = 1;
-    P[1] = pass_from_lp(&L, (uint32_t)L.frame.r_outer, (uint32_t)L.frame.r_outer);
-    // fovea :189-209
-    L.frame.factor.x = 1; L.frame.factor.y = 1; L.frame.factor.z = 1;
-    L.frame.fillSize = 1;
-    L.frame.r_outer = (float)(inner_radius + 1);
-    L.frame.r_inner = 0;
-    L.samples_per_launch = (uint32_t)cfg.spp_fovea;
-    L.frame.offset.x = L.frame.c.x - (uint32_t)(inner_radius + 1);
-    L.frame.offset.y = L.frame.c.y - (uint32_t)(inner_radius + 1);
-    L.frame.redraw = 1;
-    P[2] = pass_from_lp(&L, (uint32_t)(L.frame.r_outer * 2), (uint32_t)(L.frame.r_outer * 2));
-    rc = run_passes(c, &L, P, 3, 1);
-    L.frame.subframe_index = temp_frame;
-    L.frame.subframe_index++;
+    const uint32_t temp_frame = c->cfg.uniform ? 0u : lp->frame.subframe_index;              // :97 / :161 (FOV_OFF zeroes it first, :87)
+    const int npass = frame_passes(c->cfg, *lp, P);
+    const int rc = run_passes(c, lp, P, npass, 1);
+    lp->frame.subframe_index = temp_frame;                                                   // :128-129 / :210-211
+    lp->frame.subframe_index++;
     return rc;
+}
+
+// ---- multi-GPU: packed gather of the owned pixels ---------------------------------------------------
+int fovpt_gather_plan(fovpt_ctx* c, const fovpt_launch_params* lp, uint32_t* counts_out, int counts_len)
+{
+    if (!c || !lp) return FOVPT_E_INVALID;
+    const int world = c->cfg.world < 1 ? 1 : c->cfg.world;
+    if (world > 64) return fail(c, FOVPT_E_INVALID, "gather plans support up to 64 ranks (world = %d)", world);
+    if (lp->frame.size.x <= 0 || lp->frame.size.y <= 0) return fail(c, FOVPT_E_INVALID, "bad frame size");
+    if (counts_out && counts_len < world) return fail(c, FOVPT_E_INVALID, "counts_out holds %d entries, world is %d", counts_len, world);
+    HIPCHK(c, hipSetDevice(c->device));
+    char key[256];
+    snprintf(key, sizeof(key), "%d x %d u%d r%d/%d c%u,%u w%d t%dx%d", lp->frame.size.x, lp->frame.size.y, c->cfg.uniform, c->cfg.r_inner, c->cfg.r_outer,
+             lp->frame.c.x, lp->frame.c.y, world, c->cfg.tile_w, c->cfg.tile_h);
+    if (c->plan_key != key) {
+        fovpt_launch_params L = *lp;
+        PassDev P[3];
+        FrameDev fd;
+        memset(&fd, 0, sizeof(fd));
+        fd.npass = frame_passes(c->cfg, L, P);
+        for (int p = 0; p < fd.npass; p++) { fd.pass[p] = P[p]; fd.pass[p].row0 = 0; fd.pass[p].row1 = P[p].gh; }
+        fd.w = L.frame.size.x; fd.h = L.frame.size.y;
+        fd.cx = L.frame.c.x; fd.cy = L.frame.c.y;
+        fd.rank = c->cfg.rank; fd.world = world;
+        fd.tile_w = c->cfg.tile_w > 0 ? c->cfg.tile_w : 8; fd.tile_h = c->cfg.tile_h > 0 ? c->cfg.tile_h : 4;
+        const uint32_t npix = (uint32_t)fd.w * (uint32_t)fd.h, nblocks = (npix + FOVPT_BLOCK - 1) / FOVPT_BLOCK;
+        HIPCHK(c, c->plan_owner.reserve(npix));
+        HIPCHK(c, c->plan_blocks.reserve((size_t)nblocks * world * 4));
+        HIPCHK(c, c->plan_total.reserve(64 * 4));
+        HIPCHK(c, c->plan_base.reserve(65 * 4));
+        HIPCHK(c, c->plan_idx.reserve((size_t)npix * 4));
+        hipStream_t st = c->shadow_stream;                  // the stream frames complete on: pack / unpack run there too
+        fovpt_launch_plan_owner(st, fd, (uint8_t*)c->plan_owner.p, (uint32_t*)c->plan_blocks.p, nblocks);
+        fovpt_launch_plan_scan_fill(st, npix, nblocks, world, (const uint8_t*)c->plan_owner.p, (uint32_t*)c->plan_blocks.p,
+                                    (uint32_t*)c->plan_total.p, nullptr, nullptr, 0);
+        uint32_t total[64];
+        HIPCHK(c, hipMemcpyAsync(total, c->plan_total.p, (size_t)world * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(c, hipStreamSynchronize(st));
+        c->plan_off.assign((size_t)world + 1, 0u);
+        for (int r = 0; r < world; r++) c->plan_off[r + 1] = c->plan_off[r] + total[r];
+        HIPCHK(c, hipMemcpyAsync(c->plan_base.p, c->plan_off.data(), (size_t)(world + 1) * 4, hipMemcpyHostToDevice, st));
+        fovpt_launch_plan_scan_fill(st, npix, nblocks, world, (const uint8_t*)c->plan_owner.p, (uint32_t*)c->plan_blocks.p,
+                                    nullptr, (const uint32_t*)c->plan_base.p, (uint32_t*)c->plan_idx.p, 1);
+        HIPCHK(c, hipStreamSynchronize(st));                // (plan_off.data() must outlive the copy)
+        HIPCHK(c, hipGetLastError());
+        c->plan_key = key;
+    }
+    if (counts_out) for (int r = 0; r < world; r++) counts_out[r] = c->plan_off[r + 1] - c->plan_off[r];
+    return FOVPT_OK;
+}
+
+int fovpt_gather_pack(fovpt_ctx* c, const uint32_t* frame, uint32_t* packed)
+{
+    if (!c || !frame || !packed) return FOVPT_E_INVALID;
+    if (c->plan_key.empty()) return fail(c, FOVPT_E_INVALID, "fovpt_gather_pack without a plan (fovpt_gather_plan)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int r = c->cfg.rank;
+    if (r < 0 || (size_t)r + 1 >= c->plan_off.size()) return fail(c, FOVPT_E_INVALID, "rank %d is not part of the plan", r);
+    fovpt_launch_gather_pack(c->shadow_stream, c->plan_off[r + 1] - c->plan_off[r], (const uint32_t*)c->plan_idx.p + c->plan_off[r], frame, packed);
+    HIPCHK(c, hipGetLastError());
+    return FOVPT_OK;
+}
+
+int fovpt_gather_unpack(fovpt_ctx* c, const uint32_t* gathered, uint32_t stride, uint32_t* frame)
+{
+    if (!c || !gathered || !frame) return FOVPT_E_INVALID;
+    if (c->plan_key.empty()) return fail(c, FOVPT_E_INVALID, "fovpt_gather_unpack without a plan (fovpt_gather_plan)");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int world = (int)c->plan_off.size() - 1;
+    for (int r = 0; r < world; r++)
+        if (c->plan_off[r + 1] - c->plan_off[r] > stride) return fail(c, FOVPT_E_INVALID, "stride %u is smaller than rank %d's %u pixels", stride, r, c->plan_off[r + 1] - c->plan_off[r]);
+    fovpt_launch_gather_unpack(c->shadow_stream, world, stride, c->plan_off[world], (const uint32_t*)c->plan_base.p, (const uint32_t*)c->plan_idx.p, gathered, frame);
+    HIPCHK(c, hipGetLastError());
+    return FOVPT_OK;
 }
 
 int fovpt_synchronize(fovpt_ctx* c)

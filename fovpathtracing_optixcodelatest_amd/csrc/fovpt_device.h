@@ -185,6 +185,13 @@ void fovpt_launch_traverse(hipStream_t st, SceneView sc, PathState ps, RayQueue 
 void fovpt_launch_shade(hipStream_t st, const FrameDev& fd, SceneView sc, PathState ps, RayQueue queue_in, RayQueue queue_out,
                         ShadowQueue sq, uint32_t cap, Counters* cnt, int depth, int grid, hipEvent_t done = nullptr);
 void fovpt_launch_resolve(hipStream_t st, const FrameDev& fd, PathState ps, Counters* cnt, hipEvent_t done = nullptr);
+// multi-GPU gather plan (see wavefront.hip): owner map + per-block counts; scan (phase 0) / fill (phase 1); pack; unpack
+void fovpt_launch_plan_owner(hipStream_t st, const FrameDev& fd, uint8_t* owner, uint32_t* block_count, uint32_t nblocks);
+void fovpt_launch_plan_scan_fill(hipStream_t st, uint32_t npix, uint32_t nblocks, int world, const uint8_t* owner, uint32_t* block_count,
+                                 uint32_t* total, const uint32_t* rank_base, uint32_t* idx, int phase);
+void fovpt_launch_gather_pack(hipStream_t st, uint32_t n, const uint32_t* idx, const uint32_t* frame, uint32_t* packed);
+void fovpt_launch_gather_unpack(hipStream_t st, int world, uint32_t stride, uint32_t total, const uint32_t* base, const uint32_t* idx,
+                                const uint32_t* gathered, uint32_t* frame);
 void fovpt_launch_build_guide(hipStream_t st, const float* cdf, int n, int segments, uint32_t* guide);
 void fovpt_launch_build_cdf(hipStream_t st, int w, int h, const float4* data, float* pdfX, float* cdfX, float* pdfY, float* cdfY, float* row_total);
 void fovpt_launch_math(hipStream_t st, int op, const float* a, const float* b, float* out, size_t n);

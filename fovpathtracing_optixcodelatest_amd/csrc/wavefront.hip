@@ -1210,6 +1210,39 @@ __device__ inline void writer_range(uint32_t x, uint32_t frame_dim, uint32_t fac
     }
 }
 
+// The last writer of pixel (x, y) in the reference's launch order: the highest pass that covers it (F over M over P),
+// within a pass the launch index that comes last (ascending y, then x) among those whose clamped block fill reaches the
+// pixel (deviceProgram.cu:546-554) and that pass the ring test (:433-440).  Only launch rows [row0, row1) of a pass count
+// (a chunk of a large launch).  Used by the resolve and by the multi-GPU gather plan.
+__device__ inline bool find_last_writer(const FrameDev& fd, uint32_t x, uint32_t y, int& wp, uint32_t& wlx, uint32_t& wly)
+{
+#pragma unroll
+    for (int p = FOVPT_MAX_PASSES - 1; p >= 0; p--) {          // static indices: the pass records stay in SGPRs
+        if (p >= fd.npass) continue;
+        const PassDev& P = fd.pass[p];
+        if (P.fill <= 0) continue;
+        long long xa, xb, ya, yb, xw, yw;
+        writer_range(x, (uint32_t)fd.w, P.fx, P.fill, P.offx, P.gw, xa, xb, xw);
+        writer_range(y, (uint32_t)fd.h, P.fy, P.fill, P.offy, P.gh, ya, yb, yw);
+        if (ya < (long long)P.row0) ya = P.row0;           // only this chunk's launch rows
+        if (yb > (long long)P.row1 - 1) yb = (long long)P.row1 - 1;
+        if (yw > (long long)P.row1 - 1) yw = (long long)P.row1 - 1;
+        const long long y_end = yw >= (long long)P.row0 ? (long long)P.row0 : ya, x_end = xw >= 0 ? 0 : xa;
+        // candidates in descending launch order: [ya, yb] then the wrapped rows [row0, yw]; same along x
+        for (long long ly = yb; ly >= y_end; ly--) {
+            if (ly < ya && ly > yw) { ly = yw + 1; continue; }
+            for (long long lx = xb; lx >= x_end; lx--) {
+                if (lx < xa && lx > xw) { lx = xw + 1; continue; }
+                uint32_t ix, iy;
+                if (!ring_alive(fd, P, (uint32_t)lx, (uint32_t)ly, ix, iy)) continue;
+                wp = p; wlx = (uint32_t)lx; wly = (uint32_t)ly;
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
 // Resolve as a tiled LDS reduction.  A block owns a 64 x 4 pixel tile.
 //   A. every pixel thread finds its last writer in the reference's launch order (gather)
 //   B. runs of pixels with the same writer elect a leader; leaders are ballot-compacted into a tile-local
@@ -1245,32 +1278,12 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_resolve(const FrameDev fd, Path
     int wp = 0;
     uint32_t wli = 0, key = 0xffffffffu;
     if (inside) {
-#pragma unroll
-        for (int p = FOVPT_MAX_PASSES - 1; p >= 0; p--) {          // static indices: the pass records stay in SGPRs
-            if (p >= fd.npass || state != 0) continue;
-            const PassDev& P = fd.pass[p];
-            if (P.fill <= 0) continue;
-            long long xa, xb, ya, yb, xw, yw;
-            writer_range(x, (uint32_t)fd.w, P.fx, P.fill, P.offx, P.gw, xa, xb, xw);
-            writer_range(y, (uint32_t)fd.h, P.fy, P.fill, P.offy, P.gh, ya, yb, yw);
-            if (ya < (long long)P.row0) ya = P.row0;           // only this chunk's launch rows
-            if (yb > (long long)P.row1 - 1) yb = (long long)P.row1 - 1;
-            if (yw > (long long)P.row1 - 1) yw = (long long)P.row1 - 1;
-            const long long y_end = yw >= (long long)P.row0 ? (long long)P.row0 : ya, x_end = xw >= 0 ? 0 : xa;
-            // candidates in descending launch order: [ya, yb] then the wrapped rows [row0, yw]; same along x
-            for (long long ly = yb; ly >= y_end && state == 0; ly--) {
-                if (ly < ya && ly > yw) { ly = yw + 1; continue; }
-                for (long long lx = xb; lx >= x_end; lx--) {
-                    if (lx < xa && lx > xw) { lx = xw + 1; continue; }
-                    uint32_t ix, iy;
-                    if (!ring_alive(fd, P, (uint32_t)lx, (uint32_t)ly, ix, iy)) continue;
-                    state = launch_owned(fd, p, (uint32_t)lx, (uint32_t)ly) ? 1 : 2;
-                    wp = p;
-                    wli = ((uint32_t)ly - P.row0) * P.gw + (uint32_t)lx;
-                    key = P.launch_base + wli;
-                    break;
-                }
-            }
+        uint32_t wlx, wly;
+        if (find_last_writer(fd, x, y, wp, wlx, wly)) {
+            const PassDev& P = fd.pass[wp];
+            state = launch_owned(fd, wp, wlx, wly) ? 1 : 2;
+            wli = (wly - P.row0) * P.gw + wlx;
+            key = P.launch_base + wli;
         }
     }
     if (state != 1) key = 0xffffffffu;
@@ -1355,6 +1368,82 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_resolve(const FrameDev fd, Path
         // another rank's pixel (or, for a whole frame on a rank other than 0, nobody's): zero keeps the sum-gather exact
         fd.accum[image_index] = fovpt_float4{0.f, 0.f, 0.f, 0.f};
         fd.frame[image_index] = 0u;
+    }
+}
+
+// ---- multi-GPU: packed gather of the owned pixels -------------------------------------------------
+// Every pixel of a frame has one last writer (find_last_writer) and that launch index has one owning rank
+// (launch_owned: interleaved 8x4 launch-index tiles, the scheme of sutil/WorkDistribution.h:47-84), so the pixels of a
+// frame partition by owner.  The PLAN lists, rank by rank, the pixel indices a rank owns in ascending order; every rank
+// builds the same plan from the same launch parameters.  Per frame a rank packs its owned rgba8 words into a contiguous
+// buffer (k_gather_pack), RCCL gathers the buffers onto rank 0, and rank 0 scatters them into the frame
+// (k_gather_unpack): 1/N of the bytes of a full-frame reduce per rank.
+#define FOVPT_PLAN_NOBODY 255u
+__device__ inline uint32_t launch_owner_rank(const FrameDev& fd, int p, uint32_t lx, uint32_t ly)
+{
+    if (fd.world <= 1) return 0u;
+    const uint32_t tx = lx / (uint32_t)fd.tile_w, ty = ly / (uint32_t)fd.tile_h;
+    return (tx + 3u * ty + (uint32_t)p) % (uint32_t)fd.world;
+}
+// owner[pixel] and, per block of 256 consecutive pixels, the number of pixels every rank owns
+__global__ __launch_bounds__(FOVPT_BLOCK) void k_plan_owner(const FrameDev fd, uint8_t* __restrict__ owner, uint32_t* __restrict__ block_count)
+{
+    __shared__ uint32_t s_cnt[64];
+    if (threadIdx.x < 64) s_cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t npix = (uint32_t)fd.w * (uint32_t)fd.h;
+    const uint32_t i = blockIdx.x * FOVPT_BLOCK + threadIdx.x;
+    uint32_t o = FOVPT_PLAN_NOBODY;
+    if (i < npix) {
+        const uint32_t y = i / (uint32_t)fd.w, x = i - y * (uint32_t)fd.w;
+        int wp; uint32_t lx, ly;
+        if (find_last_writer(fd, x, y, wp, lx, ly)) o = launch_owner_rank(fd, wp, lx, ly);
+        owner[i] = (uint8_t)o;
+    }
+    if (o != FOVPT_PLAN_NOBODY) atomicAdd(&s_cnt[o], 1u);
+    __syncthreads();
+    if ((int)threadIdx.x < fd.world) block_count[(size_t)blockIdx.x * fd.world + threadIdx.x] = s_cnt[threadIdx.x];
+}
+// exclusive scan of the block counts, rank by rank (one thread per rank; built once per plan, not per frame)
+__global__ void k_plan_scan(uint32_t nblocks, int world, uint32_t* __restrict__ block_count, uint32_t* __restrict__ total)
+{
+    const int r = (int)threadIdx.x;
+    if (r >= world) return;
+    uint32_t run = 0u;
+    for (uint32_t b = 0; b < nblocks; b++) {
+        const uint32_t c = block_count[(size_t)b * world + r];
+        block_count[(size_t)b * world + r] = run;
+        run += c;
+    }
+    total[r] = run;
+}
+// idx[rank_base[o] + block offset + position among the block's pixels of the same owner] = pixel
+__global__ __launch_bounds__(FOVPT_BLOCK) void k_plan_fill(uint32_t npix, int world, const uint8_t* __restrict__ owner, const uint32_t* __restrict__ block_off,
+                                                          const uint32_t* __restrict__ rank_base, uint32_t* __restrict__ idx)
+{
+    __shared__ uint8_t s_owner[FOVPT_BLOCK];
+    const uint32_t i = blockIdx.x * FOVPT_BLOCK + threadIdx.x;
+    const uint32_t o = i < npix ? owner[i] : FOVPT_PLAN_NOBODY;
+    s_owner[threadIdx.x] = (uint8_t)o;
+    __syncthreads();
+    if (o == FOVPT_PLAN_NOBODY) return;
+    uint32_t before = 0u;
+    for (uint32_t t = 0; t < threadIdx.x; t++) before += s_owner[t] == o ? 1u : 0u;
+    idx[rank_base[o] + block_off[(size_t)blockIdx.x * world + o] + before] = i;
+}
+__global__ void k_gather_pack(uint32_t n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ frame, uint32_t* __restrict__ packed)
+{
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) packed[i] = frame[idx[i]];
+}
+// gathered: `world` buffers of `stride` words; rank r's pixels are idx[base[r] .. base[r+1])
+__global__ void k_gather_unpack(int world, uint32_t stride, const uint32_t* __restrict__ base, const uint32_t* __restrict__ idx,
+                                const uint32_t* __restrict__ gathered, uint32_t* __restrict__ frame)
+{
+    const uint32_t total = base[world];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        int r = 0;
+        while (r + 1 < world && i >= base[r + 1]) r++;
+        frame[idx[i]] = gathered[(size_t)r * stride + (i - base[r])];
     }
 }
 
@@ -1455,6 +1544,25 @@ void fovpt_launch_resolve(hipStream_t st, const FrameDev& fd, PathState ps, Coun
     dim3 grid((fd.w + 63) / 64, (fd.h + 3) / 4);
     if (done) hipExtLaunchKernelGGL(k_resolve, grid, dim3(FOVPT_BLOCK), 0, st, nullptr, done, 0, fd, ps, cnt);
     else hipLaunchKernelGGL(k_resolve, grid, dim3(FOVPT_BLOCK), 0, st, fd, ps, cnt);
+}
+void fovpt_launch_plan_owner(hipStream_t st, const FrameDev& fd, uint8_t* owner, uint32_t* block_count, uint32_t nblocks)
+{
+    hipLaunchKernelGGL(k_plan_owner, dim3(nblocks), dim3(FOVPT_BLOCK), 0, st, fd, owner, block_count);
+}
+void fovpt_launch_plan_scan_fill(hipStream_t st, uint32_t npix, uint32_t nblocks, int world, const uint8_t* owner, uint32_t* block_count,
+                                 uint32_t* total, const uint32_t* rank_base, uint32_t* idx, int phase)
+{
+    if (phase == 0) hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(64), 0, st, nblocks, world, block_count, total);
+    else hipLaunchKernelGGL(k_plan_fill, dim3(nblocks), dim3(FOVPT_BLOCK), 0, st, npix, world, owner, block_count, rank_base, idx);
+}
+void fovpt_launch_gather_pack(hipStream_t st, uint32_t n, const uint32_t* idx, const uint32_t* frame, uint32_t* packed)
+{
+    if (n) hipLaunchKernelGGL(k_gather_pack, dim3((n + 255u) / 256u < 2048u ? (n + 255u) / 256u : 2048u), dim3(256), 0, st, n, idx, frame, packed);
+}
+void fovpt_launch_gather_unpack(hipStream_t st, int world, uint32_t stride, uint32_t total, const uint32_t* base, const uint32_t* idx,
+                                const uint32_t* gathered, uint32_t* frame)
+{
+    if (total) hipLaunchKernelGGL(k_gather_unpack, dim3((total + 255u) / 256u < 2048u ? (total + 255u) / 256u : 2048u), dim3(256), 0, st, world, stride, base, idx, gathered, frame);
 }
 void fovpt_launch_build_guide(hipStream_t st, const float* cdf, int n, int segments, uint32_t* guide)
 {

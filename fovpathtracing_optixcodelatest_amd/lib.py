@@ -17,6 +17,7 @@ EXPORTS = [
     "fovpt_resize", "fovpt_get_config", "fovpt_set_config", "fovpt_launch", "fovpt_render",
     "fovpt_synchronize", "fovpt_download", "fovpt_get_stats", "fovpt_reset_stats", "fovpt_stream",
     "fovpt_probe_build_cdf", "fovpt_camera_uvw", "fovpt_debug_math", "fovpt_debug_buffer",
+    "fovpt_gather_plan", "fovpt_gather_pack", "fovpt_gather_unpack",
 ]
 
 
@@ -96,6 +97,9 @@ def load():
     L.fovpt_probe_build_cdf.argtypes = [i32, i32, vp, vp, vp, vp, vp]
     L.fovpt_camera_uvw.argtypes = [C.POINTER(abi.Float3), C.POINTER(abi.Float3), C.POINTER(abi.Float3),
                                    C.c_float, C.c_float, C.POINTER(abi.Float3), C.POINTER(abi.Float3), C.POINTER(abi.Float3)]
+    L.fovpt_gather_plan.argtypes = [vp, C.POINTER(abi.LaunchParams), vp, i32]
+    L.fovpt_gather_pack.argtypes = [vp, vp, vp]
+    L.fovpt_gather_unpack.argtypes = [vp, vp, u32, vp]
     L.fovpt_debug_math.argtypes = [vp, i32, vp, vp, vp, sz]
     L.fovpt_debug_buffer.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(sz)]
     for name in EXPORTS:

@@ -150,6 +150,20 @@ class SampleRenderer:
         """render() without the trailing synchronisation (for back-to-back timed frames)."""
         self._check(self._L.fovpt_render(self._ctx, C.byref(self.launchParams)))
 
+    # -- multi-GPU gather of the owned pixels (include/fovpt.h, fovpt_gather_*) -------------
+    def gather_plan(self):
+        """Partition of the frame's pixels by owning rank for the current config / frame size / gaze -> counts per rank."""
+        world = max(1, self.config.world)
+        counts = (C.c_uint32 * world)()
+        self._check(self._L.fovpt_gather_plan(self._ctx, C.byref(self.launchParams), counts, world))
+        return [int(x) for x in counts]
+
+    def gather_pack(self, frame_ptr, packed_ptr):
+        self._check(self._L.fovpt_gather_pack(self._ctx, frame_ptr, packed_ptr))
+
+    def gather_unpack(self, gathered_ptr, stride, frame_ptr):
+        self._check(self._L.fovpt_gather_unpack(self._ctx, gathered_ptr, stride, frame_ptr))
+
     def launch(self, width, height):
         """One optixLaunch with the current launchParams (SimplePathtracer.cpp:148-157)."""
         self._check(self._L.fovpt_launch(self._ctx, C.byref(self.launchParams), width, height))

@@ -157,7 +157,8 @@ typedef struct fovpt_config {
     int32_t world;              /* launch-index tiles t with owner(t) == rank      */
     int32_t tile_w, tile_h;     /* launch-index tile, default 8 x 4
                                    (sutil/WorkDistribution.h:47-84 scheme)         */
-    int32_t profile;            /* 1 = time each kernel with hipEvents             */
+    int32_t profile;            /* 1 = time each kernel with hipEvents; 2 = the same with every kernel
+                                   run ALONE (host synchronisation around it: serialised times)     */
     int32_t write_guides;       /* 1 = also write normal/color/albedo_buffer, the denoiser guides of
                                    PT_sv/deviceProgram.cu:555-557 (commented out in PT_sv5_, :612-614);
                                    not available with shadow-catcher materials         */
@@ -169,7 +170,7 @@ typedef struct fovpt_stats {
     uint64_t shadow_rays;       /* occlusion rays traced                           */
     uint64_t paths;             /* camera paths started                            */
     uint64_t frames;            /* fovpt_render / fovpt_launch calls               */
-    /* per-kernel device time, only filled when config.profile = 1                */
+    /* per-kernel device time, only filled when config.profile = 1 or 2           */
     double ms_generate, ms_trace, ms_shade, ms_shadow, ms_resolve;
     uint64_t n_trace_launches;  /* closest-hit kernel launches behind ms_trace     */
     uint64_t n_shadow_launches;
@@ -237,6 +238,26 @@ int fovpt_launch(fovpt_ctx* ctx, const fovpt_launch_params* lp, uint32_t width, 
  * the three passes (or the FOV_OFF pass) as ONE fused wavefront job.  Silently
  * returns FOVPT_OK when lp->frame.size.x == 0 (:81-82).  Asynchronous.            */
 int fovpt_render(fovpt_ctx* ctx, fovpt_launch_params* lp);
+
+/* ---- multi-GPU: packed gather of the final framebuffer ----------------------------------
+ * New with this library: the reference is single-GPU (SimplePathtracer.cpp:331-340).  With
+ * fovpt_config.rank/world every handle renders the launch-index tiles it owns -- interleaved
+ * 8 x 4 tiles dealt round-robin, the scheme of the SDK's unused sutil/WorkDistribution.h:47-84
+ * -- so the pixels of a frame partition by the owner of their last writer.
+ *   fovpt_gather_plan    builds (or reuses) the partition for the frame fovpt_render would
+ *                        draw with the current config and lp (frame size, gaze): per rank the
+ *                        ascending list of pixel indices it owns; counts_out[r] = their number.
+ *                        Every rank computes the same plan.  Synchronises when it rebuilds.
+ *   fovpt_gather_pack    copies THIS rank's owned rgba8 words of `frame` into `packed`
+ *                        (counts[rank] words), in plan order; asynchronous on fovpt_stream().
+ *   fovpt_gather_unpack  scatters `world` packed buffers (rank r's at gathered + r * stride)
+ *                        into `frame`; pixels nobody owns are left untouched; asynchronous.
+ * Between pack and unpack the caller moves the buffers with RCCL (gather to the root over xGMI:
+ * 1/world of the frame per rank instead of a full-frame reduce).  All pointers are device
+ * pointers.                                                                                */
+int fovpt_gather_plan(fovpt_ctx* ctx, const fovpt_launch_params* lp, uint32_t* counts_out, int counts_len);
+int fovpt_gather_pack(fovpt_ctx* ctx, const uint32_t* frame, uint32_t* packed);
+int fovpt_gather_unpack(fovpt_ctx* ctx, const uint32_t* gathered, uint32_t stride, uint32_t* frame);
 
 /* CUDA_SYNC_CHECK() (SimplePathtracer.cpp:212). */
 int fovpt_synchronize(fovpt_ctx* ctx);

@@ -756,6 +756,7 @@ struct Counters {
 //   (ii) the shadow ray of a hit whose prd.radiance / prd.alpha come out bit-identical whether it is occluded or not,
 //        or (not on a catcher) whose radiance is dropped because BSDFSample returned pdf <= 0 (:708-711 + :515).
 std::atomic<uint64_t> g_lib_radiance{0}, g_lib_shadow{0}, g_occluded{0};      // g_occluded: diagnostics, occluded shadow rays (all)
+int g_count_lib = 1;       // 0: skip the extra BSDF evaluation the counting needs on occluded rays (timed CPU baseline)
 
 struct Ctx {
     const Scene* S;
@@ -779,7 +780,7 @@ f3 SampleLightsOrShadow(const Ctx& C, const Material& material, f3 albedo, float
     if (occluded) g_occluded++;
     // the branch below is a pure function of the hit and wi (no random numbers): evaluated once, used if taken
     f3 taken = mk3(0.0f);
-    {
+    if (g_count_lib || occluded == want_occluded) {
         float bsdfPdf = BSDFPdf(material, etaI, etaO, surfaceNormal, wo, wi);
         f3 f = BSDFEval(material, albedo, etaI, etaO, surfaceNormal, wo, wi);
         if (bsdfPdf > 0.0f) {
@@ -1192,6 +1193,7 @@ void orc_lib_counts(uint64_t* out2, int reset)
     if (out2) { out2[0] = g_lib_radiance; out2[1] = g_lib_shadow; }
     if (reset) { g_lib_radiance = 0; g_lib_shadow = 0; }
 }
+void orc_set_lib_counting(int on) { g_count_lib = on ? 1 : 0; }
 uint64_t orc_occluded_count(int reset)
 {
     const uint64_t v = g_occluded;

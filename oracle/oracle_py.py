@@ -51,6 +51,12 @@ def lib():
     return _lib
 
 
+def set_lib_counting(on: bool):
+    """Counts.lib_* need one BSDF evaluation more than the reference does on occluded shadow rays; the timed CPU
+    baseline turns the counting off (the counts of such a run are meaningless)."""
+    lib().orc_set_lib_counting(1 if on else 0)
+
+
 def set_math_mode(detmath: bool):
     lib().orc_set_math_mode(1 if detmath else 0)
 

@@ -303,6 +303,58 @@ def test_three_separate_launches_per_frame_with_tile_shards():
         assert np.array_equal(sf.astype(np.uint32), ff), world
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_packed_gather_plan_pack_unpack(world):
+    """fovpt_gather_plan / _pack / _unpack (the HIP side of the multi-GPU gather): every rank computes the same plan, the
+    plan covers exactly the pixels some launch index writes, and packing every rank's frame and scattering the buffers on
+    the root reproduces the unsharded frame bit for bit -- with gaze off-centre so that the rings hang over the border."""
+    import torch
+    size = (200, 120)
+    W, H = size
+    model, probe = scenes.atrium(6000), scenes.sky_probe()
+    cfg = cfg_foveated(14, 44, (1, 2, 4))
+    gaze = (150, 40)
+    full = make_gpu(model, probe, scenes.ATRIUM_CAMERA, size, cfg, gaze=gaze)
+    full.render()
+    want, want_acc = full.downloadPixels(), full.downloadAccum()
+    full.close()
+    plans, packed, root = [], [], None
+    for rank in range(world):
+        c = cfg.copy()
+        c.rank, c.world = rank, world
+        r = make_gpu(model, probe, scenes.ATRIUM_CAMERA, size, c, gaze=gaze)
+        counts = r.gather_plan()
+        assert counts == r.gather_plan()                              # cached, stable
+        plans.append(counts)
+        r.render()
+        stride = (max(counts) + 63) // 64 * 64
+        buf = torch.full((stride,), -1, dtype=torch.int32, device="cuda")
+        r.gather_pack(r.launchParams.frame.frame_buffer, buf.data_ptr())
+        r.synchronize()
+        packed.append(buf.cpu())
+        if rank == 0:
+            root = r
+        else:
+            r.close()
+    assert all(p == plans[0] for p in plans)
+    assert sum(plans[0]) == int((want_acc[..., 3] == 1).sum())          # exactly the pixels that have a writer
+    assert max(plans[0]) - min(plans[0]) < 0.25 * max(plans[0])           # interleaved tiles balance the pixel counts too
+    stride = packed[0].numel()
+    gathered = torch.stack(packed).to("cuda")
+    target = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+    root.gather_unpack(gathered.data_ptr(), stride, target.data_ptr())
+    root.synchronize()
+    got = target.cpu().numpy().view(np.uint32).reshape(H, W)
+    assert np.array_equal(got, want)
+    # uniform frames (FOV_OFF) partition too
+    cu = cfg_uniform(1, 2)
+    cu.rank, cu.world = 0, world
+    root.config = cu
+    counts = root.gather_plan()
+    assert sum(counts) == W * H and max(counts) - min(counts) <= 0.15 * max(counts)
+    root.close()
+
+
 def test_stereo_asymmetric_frusta(oracle):
     """Two eyes = two cameras and two render() calls per frame (BASELINE.json configs[4]); per-eye off-centre
     frusta enter only through camera U, V, W, so the oracle sees the same LaunchParams."""

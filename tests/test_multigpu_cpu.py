@@ -54,3 +54,49 @@ def test_gloo_sum_gather_reproduces_frame(tmp_path):
     mp.spawn(_worker, args=(2, port, path), nprocs=2, join=True)
     out = np.load(path + ".out.npy")
     assert np.array_equal(out, full)
+
+
+def _worker_packed(rank, world, port, path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    full = np.load(path)
+    own = _owner_image(full.shape[1], full.shape[0], world)
+    own[3:5, 7:19] = 255                                          # a few pixels nobody writes (holes between the rings)
+    plan = multigpu.plan_from_owner_map(own, world)
+    counts = [len(p) for p in plan]
+    stride = (max(counts) + 63) // 64 * 64
+    mine = np.where(own == rank, full, 0).astype(np.int32)        # what this rank rendered: zero outside its pixels
+    packed = torch.from_numpy(mine.reshape(-1)[plan[rank]].copy())
+    g = multigpu.gather_packed(packed, stride, dst=0)
+    if rank == 0:
+        out = np.full(full.size, -7, np.int32)                    # holes keep what the root's buffer held
+        for r in range(world):
+            out[plan[r]] = g[r, :counts[r]].numpy()
+        np.save(path + ".packed.npy", out.reshape(full.shape))
+        np.save(path + ".bytes.npy", np.array([stride * 4, full.size * 4]))
+    else:
+        assert g is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_packed_gather_reproduces_frame(tmp_path):
+    """The packed gather (pack owned pixels -> gather -> scatter on the root) over gloo with two ranks: the root ends up
+    with every rank's pixels, holes untouched, and each rank sends about half a frame instead of a whole one."""
+    rng = np.random.default_rng(1)
+    full = rng.integers(1, 2 ** 31 - 1, size=(64, 96), dtype=np.int32)
+    path = str(tmp_path / "full.npy")
+    np.save(path, full)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker_packed, args=(2, port, path), nprocs=2, join=True)
+    out = np.load(path + ".packed.npy")
+    own = _owner_image(96, 64, 2)
+    hole = np.zeros_like(own, bool)
+    hole[3:5, 7:19] = True
+    assert np.array_equal(out[~hole], full[~hole]) and (out[hole] == -7).all()
+    sent, whole = np.load(path + ".bytes.npy")
+    assert sent < 0.6 * whole
