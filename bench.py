@@ -122,13 +122,13 @@ def run_counter_passes(timeout_s=150):
     return out, "rocprofv3 --pmc child passes of this run (kernels serialised by the profiler)"
 
 
-def build_renderer(renderer, scenes, abi, tris, local_rank, rank, world, probe_kind="constant", seed=1234):
-    model = scenes.atrium(tris, seed=seed, material="app")
+def build_renderer(renderer, scenes, abi, tris, local_rank, rank, world, probe_kind="constant", seed=1234, scene="atrium"):
+    model = scenes.atrium(tris, seed=seed, material="app") if scene == "atrium" else scenes.street(tris, material="app")
     # loadColor at frame resolution (main.cpp:175-187,229), or a seeded non-constant HDR sky of the same size
     probe_data = scenes.ambient_probe(W, H, 2.5) if probe_kind == "constant" else scenes.sky_probe(W, H, seed=11)
     r = renderer.SampleRenderer(model, device=local_rank)
     r.resize((W, H))
-    cam = scenes.ATRIUM_CAMERA
+    cam = scenes.ATRIUM_CAMERA if scene == "atrium" else scenes.STREET_CAMERA
     r.setCamera(renderer.Camera(cam["eye"], cam["lookat"], cam["up"], cam["fovy"], W / float(H)))
     probe = renderer.ProbeData(probe_data).BuildCDF()
     r.setProbe(probe)
@@ -514,8 +514,10 @@ def main():
         variants["hdr_probe_moving_camera_and_gaze_advancing_subframe"] = time_frames(rv, vf, move)
         rv.close()
         # (c) north_star's "~1 M-triangle scene" and the Bistro-class 3.8 M one, same frame settings
-        for name, tris in (("scene_1m_tris", 1000000), ("scene_3p8m_tris", 3800000)):
-            rv, _, mv, _, _ = build_renderer(renderer, scenes, abi, tris, local_rank, 0, 1)
+        # and the open street of facade modules and foliage cards (depth complexity, long rays) under the HDR sky
+        for name, tris, scn, pk in (("scene_1m_tris", 1000000, "atrium", "constant"), ("scene_3p8m_tris", 3800000, "atrium", "constant"),
+                                    ("street_3p8m_tris_hdr_probe", 3800000, "street", "hdr")):
+            rv, _, mv, _, _ = build_renderer(renderer, scenes, abi, tris, local_rank, 0, 1, probe_kind=pk, scene=scn)
 
             def reset2(_k, rr=rv):
                 rr.launchParams.frame.subframe_index = 0

@@ -7,6 +7,7 @@ import ctypes as C
 
 FOVPT_OK = 0
 MATERIAL_FLAG_SHADOW_CATCHER = 1
+OPT_SKY_MISS, OPT_RUSSIAN_ROULETTE = 1, 2      # fovpt_config.options (include/fovpt.h)
 
 OP_SIN, OP_COS, OP_ACOS, OP_ATAN2, OP_LOG, OP_POW, OP_SQRT, OP_DIV, OP_RSQRTD, OP_UNORM8 = range(1, 11)
 
@@ -136,7 +137,7 @@ class Config(C.Structure):
         ("spp_periphery", C.c_int32), ("spp_middle", C.c_int32), ("spp_fovea", C.c_int32),
         ("spp_uniform", C.c_int32), ("max_depth", C.c_int32), ("accumulate", C.c_int32),
         ("rank", C.c_int32), ("world", C.c_int32), ("tile_w", C.c_int32), ("tile_h", C.c_int32),
-        ("profile", C.c_int32), ("write_guides", C.c_int32), ("reserved", C.c_int32 * 1),
+        ("profile", C.c_int32), ("write_guides", C.c_int32), ("options", C.c_int32),
     ]
 
     @classmethod

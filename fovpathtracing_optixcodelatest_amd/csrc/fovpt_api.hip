@@ -326,6 +326,7 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     fd.total_slots = (uint32_t)slots;
     fd.max_depth = c->cfg.max_depth;
     fd.accumulate = c->cfg.accumulate;
+    fd.options = c->cfg.options;
     fd.rank = c->cfg.rank; fd.world = c->cfg.world < 1 ? 1 : c->cfg.world;
     fd.tile_w = c->cfg.tile_w > 0 ? c->cfg.tile_w : 8; fd.tile_h = c->cfg.tile_h > 0 ? c->cfg.tile_h : 4;
 
@@ -786,6 +787,7 @@ int fovpt_set_config(fovpt_ctx* c, const fovpt_config* cfg)
     if (cfg->world < 1 || cfg->rank < 0 || cfg->rank >= cfg->world) return fail(c, FOVPT_E_INVALID, "bad rank/world %d/%d", cfg->rank, cfg->world);
     if (cfg->spp_periphery < 1 || cfg->spp_middle < 1 || cfg->spp_fovea < 1 || cfg->spp_uniform < 1) return fail(c, FOVPT_E_INVALID, "spp must be >= 1");
     if (cfg->r_inner < 0 || cfg->r_outer < cfg->r_inner) return fail(c, FOVPT_E_INVALID, "bad radii");
+    if (cfg->options & ~(FOVPT_OPT_SKY_MISS | FOVPT_OPT_RUSSIAN_ROULETTE)) return fail(c, FOVPT_E_INVALID, "unknown option bits %d", cfg->options);
     c->cfg = *cfg;
     return FOVPT_OK;
 }

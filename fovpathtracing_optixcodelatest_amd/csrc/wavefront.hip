@@ -980,6 +980,9 @@ __device__ inline float4 tex2d(const TexDev& T, float u, float v)
 #ifndef FOVPT_V_SHADEWAVES
 #define FOVPT_V_SHADEWAVES 1
 #endif
+// EXTRA: the build of the kernel that also knows the opt-in extensions of fovpt_config.options (sky radiance for escaped
+// secondary rays, Russian roulette); the default build carries none of their code or registers.
+template <bool EXTRA>
 __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const FrameDev fd, SceneView sc, PathState ps,
                                                        RayQueue queue_in, RayQueue queue_out,
                                                        ShadowQueue sq, uint32_t cap, Counters* __restrict__ cnt, int depth_iter)
@@ -993,6 +996,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
         bool want_shadow = false, want_next = false;
         uint32_t slot = 0;
         V3 next_o = v3(0.f), next_d = v3(0.f);
+        float next_pdf = 0.f;          // prd.bsdfPdf of the sample that sends the next ray (read by FOVPT_OPT_SKY_MISS only)
         float4 sh_o, sh_d, sh_vis, sh_occ;
         sh_o = sh_d = sh_vis = sh_occ = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < n) {
@@ -1007,6 +1011,26 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
             if (tpos == 0xffffffffu) {
                 // __miss__radiance :253-282: DONE; nothing is added for this segment (:515 breaks first)
                 flags |= FLAG_DONE;
+                if (EXTRA && (fd.options & FOVPT_OPT_SKY_MISS) && (flags & FLAG_SECONDARY) && depth < fd.max_depth) {
+                    // the block the reference carries commented out (:259-269): MIS counterpart of SampleLights; the
+                    // segment is counted (one more radiance cell), see include/fovpt.h
+                    const V3 dir = v3(d4);
+                    const float bsdfPdf = d4.w;                                            // pdf of the sample that sent this ray
+                    const V3 thr = v3(ps.thr[slot]);
+                    float u, v;
+                    probe_dir_to_uv(dir, u, v);
+                    const fovpt_probe& pr = fd.probe;                                      // ProbePdf, Probe.cuh:69-93
+                    const int col = max(0, min((int)(u * pr.width), pr.width - 1));
+                    const int row = max(0, min((int)(v * pr.height), pr.height - 1));
+                    float skyPdf = pr.pdfValuesX[row * fd.probe_row_mul * pr.width + col] * pr.pdfValuesY[row];
+                    const float sinTheta = fovpt_dm_sinf(v * kPi);
+                    if (fabsf(sinTheta) < 0.0001f) skyPdf = 0.0f;
+                    else skyPdf *= float(pr.width) * float(pr.height) / (2.0f * kPi * kPi * sinTheta);
+                    const float weight = 0.5f * bsdfPdf / (0.5f * bsdfPdf + 0.5f * skyPdf);
+                    const V3 rad = v3(0.f) + (weight * v3(probe_eval(pr, fd.probe_row_mul, u, v))) * thr;
+                    ps.rad[(size_t)slot * ps.stride + depth] = f4(rad, 0.f);
+                    depth += 1;
+                }
             } else {
                 const V3 ray_o = v3(o4), ray_dir = v3(d4);
                 // ProbeSample is the first consumer of the path's random numbers on a shaded hit (:303-344) and
@@ -1028,7 +1052,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
                 if (catcher && (flags & FLAG_SECONDARY)) {
                     // :646-651: pass straight through, depth unchanged after the loop's ++depth;
                     // the loop adds prd.radiance == 0 to direct/indirect, which changes nothing
-                    next_o = P; next_d = ray_dir;
+                    next_o = P; next_d = ray_dir; next_pdf = d4.w;
                     want_next = true;
                 } else if (depth >= fd.max_depth) {
                     // the reference's discarded last segment (:515).  It is only traced here when the
@@ -1129,8 +1153,14 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
                         // The reference traces once more at depth == max_depth and throws the result
                         // away (:515).  Without a shadow catcher in the scene that segment cannot
                         // change anything (alpha is already 1), so it is not traced.
-                        if (depth < fd.max_depth || sc.any_catcher) {
-                            next_o = P; next_d = bsdfDir;
+                        bool rr_kill = false;
+                        if (EXTRA && (fd.options & FOVPT_OPT_RUSSIAN_ROULETTE) && depth >= 2) {   // the //!TODO of :518-520, see include/fovpt.h
+                            const float q = fmaxf(0.05f, fminf(1.0f, fmaxf(thr.x, fmaxf(thr.y, thr.z))));
+                            if (rng.randf() >= q) rr_kill = true;
+                            else thr = thr * (1.0f / q);
+                        }
+                        if (!rr_kill && (depth < fd.max_depth || sc.any_catcher)) {
+                            next_o = P; next_d = bsdfDir; next_pdf = bsdfPdf;
                             ps.thr[slot] = f4(thr, rayEta);
                             want_next = true;
                         }
@@ -1145,7 +1175,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
         uint32_t spos, qpos;
         block_append2(cnt, FOVPT_CNT_SQ(depth_iter), want_shadow, FOVPT_CNT_Q(depth_iter + 1), want_next, cap, s_scratch, spos, qpos);
         if (want_shadow) { sq.o[spos] = sh_o; sq.d[spos] = sh_d; sq.val_vis[spos] = sh_vis; sq.val_occ[spos] = sh_occ; }
-        if (want_next) { queue_out.o[qpos] = f4(next_o, __uint_as_float(slot)); queue_out.d[qpos] = f4(next_d, 0.f); }
+        if (want_next) { queue_out.o[qpos] = f4(next_o, __uint_as_float(slot)); queue_out.d[qpos] = f4(next_d, next_pdf); }
     }
 }
 
@@ -1536,8 +1566,13 @@ void fovpt_launch_traverse(hipStream_t st, SceneView sc, PathState ps, RayQueue 
 void fovpt_launch_shade(hipStream_t st, const FrameDev& fd, SceneView sc, PathState ps, RayQueue queue_in, RayQueue queue_out,
                         ShadowQueue sq, uint32_t cap, Counters* cnt, int depth, int grid, hipEvent_t done)
 {
-    if (done) hipExtLaunchKernelGGL(k_shade, dim3(grid), dim3(FOVPT_BLOCK), 0, st, nullptr, done, 0, fd, sc, ps, queue_in, queue_out, sq, cap, cnt, depth);
-    else hipLaunchKernelGGL(k_shade, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, sc, ps, queue_in, queue_out, sq, cap, cnt, depth);
+    if (fd.options) {
+        if (done) hipExtLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(FOVPT_BLOCK), 0, st, nullptr, done, 0, fd, sc, ps, queue_in, queue_out, sq, cap, cnt, depth);
+        else hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, sc, ps, queue_in, queue_out, sq, cap, cnt, depth);
+    } else {
+        if (done) hipExtLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(FOVPT_BLOCK), 0, st, nullptr, done, 0, fd, sc, ps, queue_in, queue_out, sq, cap, cnt, depth);
+        else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, sc, ps, queue_in, queue_out, sq, cap, cnt, depth);
+    }
 }
 void fovpt_launch_resolve(hipStream_t st, const FrameDev& fd, PathState ps, Counters* cnt, hipEvent_t done)
 {

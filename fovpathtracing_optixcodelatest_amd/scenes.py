@@ -274,6 +274,160 @@ def atrium(target_triangles: int = 262144, seed: int = 1234, material="app", tol
     return best
 
 
+STREET_CAMERA = dict(eye=(-2300.0, 170.0, 40.0), lookat=(0.0, 330.0, 0.0), up=(0.0, 1.0, 0.0), fovy=55.0)
+
+
+def street(target_triangles: int = 3800000, seed: int = 4321, material="app", tolerance=0.01) -> Model:
+    """Bistro-class exterior: a street 5200 units long between two rows of 20 facade modules each
+    (relief walls, recessed windows with sills and glass, balconies with baluster rows, cornices, awnings), a cobbled
+    road with kerbs, lamp posts with emissive lanterns, planters, and 14 trees whose crowns are thousands of opaque
+    foliage cards (no alpha: the reference has no cut-outs either).  Unlike the atrium hall it is open to the sky, seen
+    along its length (long rays, many candidate layers in depth: cards, balusters, posts), and most triangles are small
+    relative to the boxes around them.  The tessellation factor is solved for the triangle count like atrium()."""
+    mk = {"app": app_default, "diffuse": diffuse_only, "matte": matte}[material]
+
+    def build(s):
+        rng = np.random.default_rng(seed)
+        M = Model()
+        for k in range(8):
+            M.textures.append(_texture(k % 4, rng))
+        colors = rng.random((32, 3)) * 0.55 + 0.3
+        mats = [mk(tuple(c)) for c in colors]
+        leaf_mats = [mk((0.15 + 0.2 * rng.random(), 0.45 + 0.4 * rng.random(), 0.1 + 0.15 * rng.random())) for _ in range(4)]
+        n = lambda base: max(1, int(round(base * s)))
+
+        def add(vtc, mat, tex=-1):
+            v, i, tc = vtc
+            M.meshes.append(TriangleMesh(v, i, mat if isinstance(mat, Material) else mats[mat % 32], tc, tex))
+
+        def box(x0, x1, y0, y1, z0, z1, mat, res=(1, 1, 1), tex=-1):
+            """six tessellated faces, outward normals"""
+            rx, ry, rz = res
+            add(_grid(rx, ry, lambda U, V: (x0 + (x1 - x0) * U, y0 + (y1 - y0) * V, z1 + 0 * U)), mat, tex)                 # +z
+            add(_grid(rx, ry, lambda U, V: (x0 + (x1 - x0) * U, y0 + (y1 - y0) * V, z0 + 0 * U), flip=True), mat, tex)      # -z
+            add(_grid(rz, ry, lambda U, V: (x1 + 0 * U, y0 + (y1 - y0) * V, z0 + (z1 - z0) * U), flip=True), mat, tex)      # +x
+            add(_grid(rz, ry, lambda U, V: (x0 + 0 * U, y0 + (y1 - y0) * V, z0 + (z1 - z0) * U)), mat, tex)                 # -x
+            add(_grid(rx, rz, lambda U, V: (x0 + (x1 - x0) * U, y1 + 0 * U, z0 + (z1 - z0) * V), flip=True), mat, tex)      # +y
+            add(_grid(rx, rz, lambda U, V: (x0 + (x1 - x0) * U, y0 + 0 * U, z0 + (z1 - z0) * V)), mat, tex)                 # -y
+
+        def cylinder(xc, zc, y0, y1, rad, mat, nu, nv, bulge=0.0):
+            add(_grid(nu, nv, lambda U, V: (xc + rad * (1 + bulge * np.sin(np.pi * V)) * np.cos(2 * np.pi * U), y0 + (y1 - y0) * V,
+                                            zc + rad * (1 + bulge * np.sin(np.pi * V)) * np.sin(2 * np.pi * U)), flip=True), mat)
+
+        X0, X1, ZW = -2600.0, 2600.0, 420.0            # street axis along x, facades at z = +-ZW
+        # road: cobbles (displaced), two kerbs and pavements
+        ph = rng.random(2) * 6.28
+        add(_grid(n(260), n(36), lambda U, V: (X0 + (X1 - X0) * U, 2.5 * np.sin(U * 900 + ph[0]) * np.sin(V * 130 + ph[1]) - 2.0,
+                                               -260 + 520 * V), flip=True), 0, 1)
+        for sgn in (-1.0, 1.0):
+            box(X0, X1, 0.0, 14.0, sgn * 260 - 12, sgn * 260 + 12, 1, (n(60), 1, 1))
+            add(_grid(n(200), n(12), lambda U, V, sgn=sgn: (X0 + (X1 - X0) * U, 14.0 + 0.6 * np.sin(U * 400) * np.sin(V * 40),
+                                                            sgn * 272 + sgn * (ZW - 272) * V), flip=sgn > 0), 2, 0)
+        # facades: 20 modules per side, 260 wide, 3-5 storeys
+        nmod = 20
+        for side, sgn in enumerate((-1.0, 1.0)):
+            for m in range(nmod):
+                mrng = np.random.default_rng(seed + 1000 * side + m)
+                xa = X0 + (X1 - X0) * m / nmod
+                xb = xa + (X1 - X0) / nmod
+                storeys = int(mrng.integers(3, 6))
+                hs = 300.0 + 40.0 * mrng.random()
+                height = storeys * hs + 80.0
+                zf = sgn * ZW
+                wall_mat = 3 + int(mrng.integers(0, 8))
+                amp, f1, f2 = 3.0 + 5.0 * mrng.random(), 30 + 60 * mrng.random(), 20 + 40 * mrng.random()
+                # relief wall facing the street
+                add(_grid(n(40), n(14 * storeys), lambda U, V, xa=xa, xb=xb, height=height, zf=zf, amp=amp, f1=f1, f2=f2, sgn=sgn: (
+                    xa + (xb - xa) * U, height * V, zf - sgn * amp * (np.sin(U * f1) * np.sin(V * f2 * storeys / 3.0) + 1.0)),
+                    flip=sgn < 0), wall_mat, 1 + (m % 3))
+                # roof slab and side fins between modules (occlusion in depth along the street)
+                box(xa, xb, height, height + 25.0, zf - 40 * (sgn < 0) - 0.0, zf + 40 * (sgn > 0) + 0.0, 11, (n(8), 1, 1))
+                box(xa - 6, xa + 6, 0.0, height, min(zf, zf - sgn * 30), max(zf, zf - sgn * 30), 12, (1, n(4 * storeys), 1))
+                # cornice
+                add(_grid(n(30), n(6), lambda U, V, xa=xa, xb=xb, height=height, zf=zf, sgn=sgn: (
+                    xa + (xb - xa) * U, height - 30 + 30 * V, zf - sgn * (10 + 28 * np.sin(np.pi * V) ** 2)), flip=sgn < 0), 13)
+                nwin = 3
+                for st_ in range(storeys):
+                    y0 = 70.0 + st_ * hs
+                    for wv in range(nwin):
+                        xc = xa + (xb - xa) * (wv + 0.5) / nwin
+                        ww, wh = 46.0, 150.0
+                        # window: sill, two jambs, lintel, glass pane set back from the wall
+                        box(xc - ww - 8, xc + ww + 8, y0 - 10, y0, min(zf - sgn * 26, zf), max(zf - sgn * 26, zf), 14, (n(3), 1, 1))
+                        box(xc - ww - 8, xc - ww, y0, y0 + wh, min(zf - sgn * 16, zf), max(zf - sgn * 16, zf), 14, (1, n(3), 1))
+                        box(xc + ww, xc + ww + 8, y0, y0 + wh, min(zf - sgn * 16, zf), max(zf - sgn * 16, zf), 14, (1, n(3), 1))
+                        box(xc - ww - 8, xc + ww + 8, y0 + wh, y0 + wh + 12, min(zf - sgn * 20, zf), max(zf - sgn * 20, zf), 14, (n(3), 1, 1))
+                        add(_grid(n(4), n(8), lambda U, V, xc=xc, ww=ww, y0=y0, wh=wh, zf=zf, sgn=sgn: (
+                            xc - ww + 2 * ww * U, y0 + wh * V, zf - sgn * 4.0 + 0 * U), flip=sgn < 0), 15)
+                    # balcony on some storeys: slab + a row of balusters + rail
+                    if st_ > 0 and mrng.random() < 0.55:
+                        yb = y0 - 14.0
+                        z_in, z_out = zf, zf - sgn * 70.0
+                        box(xa + 20, xb - 20, yb, yb + 8, min(z_in, z_out), max(z_in, z_out), 16, (n(10), 1, n(2)))
+                        nb = n(22)
+                        for b in range(nb):
+                            xbp = xa + 26 + (xb - xa - 52) * b / max(1, nb - 1)
+                            cylinder(xbp, z_out + sgn * 4, yb + 8, yb + 60, 2.2, 17, max(5, n(6)), max(1, n(3)), bulge=0.5)
+                        box(xa + 20, xb - 20, yb + 60, yb + 66, min(z_out, z_out + sgn * 8), max(z_out, z_out + sgn * 8), 17, (n(10), 1, 1))
+                # ground floor awning (sagging cloth)
+                if mrng.random() < 0.6:
+                    add(_grid(n(24), n(10), lambda U, V, xa=xa, xb=xb, zf=zf, sgn=sgn: (
+                        xa + 30 + (xb - xa - 60) * U, 250 - 60 * V - 10 * np.sin(np.pi * U) * V - 4 * np.sin(U * 50) * V, zf - sgn * 130 * V),
+                        flip=sgn > 0), 18 + (m % 6), 4 + (m % 4))
+        # lamp posts with emissive lanterns, planters
+        for k in range(16):
+            xc = X0 + 160 + (X1 - X0 - 320) * k / 15.0
+            zc = 300.0 if k % 2 else -300.0
+            cylinder(xc, zc, 14.0, 420.0, 5.0, 24, max(6, n(10)), max(2, n(12)))
+            v, i, tc = _grid(max(6, n(12)), max(4, n(8)), lambda U, V, xc=xc, zc=zc: (
+                xc + 22 * np.sin(np.pi * V) * np.cos(2 * np.pi * U), 440 + 26 * np.cos(np.pi * V), zc + 22 * np.sin(np.pi * V) * np.sin(2 * np.pi * U)))
+            M.meshes.append(TriangleMesh(v, i, mk((1.0, 0.9, 0.7)) if material != "app" else app_default((1.0, 0.9, 0.7), (5.0, 4.2, 3.0)), tc, -1))
+            box(xc + 60, xc + 150, 14.0, 60.0, zc - 30, zc + 30, 25, (n(4), n(2), n(2)), 2)
+        # trees: trunk, a few branches, crowns of opaque foliage cards
+        for k in range(14):
+            trng = np.random.default_rng(seed + 5000 + k)
+            xc = X0 + 300 + (X1 - X0 - 600) * k / 13.0 + 40 * (trng.random() - 0.5)
+            zc = (200.0 if k % 2 else -200.0) + 30 * (trng.random() - 0.5)
+            th = 330.0 + 120.0 * trng.random()
+            cylinder(xc, zc, 14.0, th, 14.0, 26, max(6, n(12)), max(3, n(14)), bulge=-0.25)
+            ncards = n(3600) * 4 // 4
+            c = np.stack([xc + 170 * trng.normal(size=ncards) * 0.55, th + 110 + 130 * trng.normal(size=ncards) * 0.55,
+                          zc + 170 * trng.normal(size=ncards) * 0.55], axis=1)
+            a = trng.normal(size=(ncards, 3)); a /= np.linalg.norm(a, axis=1, keepdims=True)
+            b = np.cross(a, trng.normal(size=(ncards, 3))); b /= np.linalg.norm(b, axis=1, keepdims=True)
+            sz = (9.0 + 9.0 * trng.random(ncards))[:, None]
+            quad = np.stack([c - a * sz - b * sz, c + a * sz - b * sz, c + a * sz + b * sz, c - a * sz + b * sz], axis=1)   # (n,4,3)
+            v = quad.reshape(-1, 3).astype(np.float32)
+            base = (4 * np.arange(ncards, dtype=np.uint32))[:, None]
+            idx = np.concatenate([base + np.uint32([0, 1, 2]), base + np.uint32([0, 2, 3])], axis=0).astype(np.uint32)
+            tcq = np.tile(np.float32([[0, 0], [1, 0], [1, 1], [0, 1]]), (ncards, 1))
+            M.meshes.append(TriangleMesh(v, idx, leaf_mats[k % 4], tcq, -1))
+        # one mesh per (material, texture), as loadOBJ would deliver a modelled street (Model.cpp:166-206)
+        groups = {}
+        for mesh in M.meshes:
+            groups.setdefault((id(mesh.material), mesh.texture_id), []).append(mesh)
+        merged = []
+        for (_, tex), ms in groups.items():
+            v, i = _merge([(m_.vertex, m_.index) for m_ in ms])
+            tc = np.concatenate([m_.texcoord for m_ in ms]).astype(np.float32)
+            merged.append(TriangleMesh(v, i, ms[0].material, tc, tex))
+        M.meshes = merged
+        return M
+
+    s = np.sqrt(target_triangles / 3800000.0)
+    best, best_err = None, None
+    for _ in range(20):
+        model = build(s)
+        cnt = model.num_triangles
+        err = abs(cnt - target_triangles)
+        if best is None or err < best_err:
+            best, best_err = model, err
+        if err <= tolerance * target_triangles:
+            break
+        s *= (target_triangles / cnt) ** 0.4
+    return best
+
+
 def ambient_probe(width, height, value=2.5):
     """loadColor (PT_sv5_/main.cpp:175-187): a constant-colour probe at frame resolution."""
     data = np.empty((height, width, 4), dtype=np.float32)

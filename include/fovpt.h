@@ -162,8 +162,21 @@ typedef struct fovpt_config {
     int32_t write_guides;       /* 1 = also write normal/color/albedo_buffer, the denoiser guides of
                                    PT_sv/deviceProgram.cu:555-557 (commented out in PT_sv5_, :612-614);
                                    not available with shadow-catcher materials         */
-    int32_t reserved[1];
+    int32_t options;            /* opt-in extensions beyond the reference's behaviour (0 = PT_sv5_ as shipped):
+                                   FOVPT_OPT_SKY_MISS, FOVPT_OPT_RUSSIAN_ROULETTE                     */
 } fovpt_config;
+
+/* fovpt_config.options.  Both are NON-PARITY modes with respect to the reference (it has neither); the CPU oracle
+ * implements them identically, so the GPU is still checked bit for bit against it.
+ *  SKY_MISS          the multiple-importance-sampling counterpart of SampleLights that PT_sv5_ carries commented out
+ *                    in __miss__radiance (deviceProgram.cu:259-269, :273-278): a SECONDARY ray that escapes adds
+ *                    w * ProbeEval(dir) * pathThroughput, w = bsdfPdf / (bsdfPdf + ProbePdf(dir)) (Probe.cuh:69-93), and the
+ *                    path loop counts that segment although it is DONE (the reference's break at :515 would drop it).
+ *  RUSSIAN_ROULETTE  the //!TODO of deviceProgram.cu:518-520: from the second bounce on a path survives a shaded hit
+ *                    with probability q = clamp(max component of pathThroughput, 0.05, 1), decided by one more
+ *                    Random::Randf() after BSDFSample's draws; survivors carry pathThroughput / q.                */
+#define FOVPT_OPT_SKY_MISS 1
+#define FOVPT_OPT_RUSSIAN_ROULETTE 2
 
 typedef struct fovpt_stats {
     uint64_t radiance_rays;     /* closest-hit rays traced since last reset        */

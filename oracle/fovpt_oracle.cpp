@@ -244,6 +244,17 @@ inline void ProbeSample(const ProbeH& image, f3& dir, f3& color, float& pdf, Ran
     f2 uv = {u, v};
     dir = ProbeUVToDir(uv);
 }
+inline float ProbePdf(const ProbeH& image, const f3& d)                       // Probe.cuh:69-93 (used by FOVPT_OPT_SKY_MISS only)
+{
+    f2 uv = ProbeDirToUV(d);
+    int col = clampi(int(uv.x * image.width), 0, image.width - 1);
+    int row = clampi(int(uv.y * image.height), 0, image.height - 1);
+    float pdf = image.pdfX[row * image.width + col] * image.pdfY[row];
+    float sinTheta = m_sinf(uv.y * kPi);
+    if (fabsf(sinTheta) < 0.0001f) pdf = 0.0f;
+    else pdf *= float(image.width) * float(image.height) / (2.0f * kPi * kPi * sinTheta);
+    return pdf;
+}
 inline float Luminance(const f4& c) { return c.x * 0.3f + c.y * 0.6f + c.z * 0.1f; }   // maths.h:165-168
 
 void BuildCDF(int width, int height, const f4* data, float* pdfX, float* cdfX, float* pdfY, float* cdfY)  // Probe.h:29-77
@@ -736,6 +747,8 @@ struct RadiancePRD {                                // :60-89
     int depth;
     int stateFlags;
     Random rand;
+    bool sky_added = false;    // FOVPT_OPT_SKY_MISS: this (escaped, secondary) segment carries sky radiance to be counted
+    bool rr_kill = false;      // FOVPT_OPT_RUSSIAN_ROULETTE: the path ends after this segment
 };
 
 struct Opts {
@@ -744,6 +757,7 @@ struct Opts {
     int brute;
     int nthreads;
     int write_guides;    // PT_sv/deviceProgram.cu:555-557 (commented out in PT_sv5_/deviceProgram.cu:612-614)
+    int options = 0;     // fovpt_config.options: FOVPT_OPT_SKY_MISS | FOVPT_OPT_RUSSIAN_ROULETTE (not in the reference)
 };
 struct Counters {
     std::atomic<uint64_t> radiance_rays{0}, shadow_rays{0}, paths{0};
@@ -756,6 +770,7 @@ struct Counters {
 //   (ii) the shadow ray of a hit whose prd.radiance / prd.alpha come out bit-identical whether it is occluded or not,
 //        or (not on a catcher) whose radiance is dropped because BSDFSample returned pdf <= 0 (:708-711 + :515).
 std::atomic<uint64_t> g_lib_radiance{0}, g_lib_shadow{0}, g_occluded{0};      // g_occluded: diagnostics, occluded shadow rays (all)
+int g_options = 0;         // fovpt_config.options for the launches that follow (orc_render sets it from its cfg)
 int g_count_lib = 1;       // 0: skip the extra BSDF evaluation the counting needs on occluded rays (timed CPU baseline)
 
 struct Ctx {
@@ -805,7 +820,16 @@ void traceRadiance(const Ctx& C, const f3& ray_origin, const f3& ray_dir, Radian
     const Scene& S = *C.S;
     nrad++;
     Hit h = trace_closest(S, ray_origin, ray_dir, kTmin, kTmax, C.opt.brute);
+    prd->sky_added = false; prd->rr_kill = false;
     if (h.prim == NO_HIT) {                                         // __miss__radiance
+        if ((C.opt.options & FOVPT_OPT_SKY_MISS) && (prd->stateFlags & RAY_STATE_FLAGS_SECONDARY_RAY)) {
+            // the block the reference carries commented out (:259-269), with the balance-heuristic constants of
+            // SampleLights (:331-335; the commented code's integer 1 / 2 would make the weight zero)
+            const float skyPdf = ProbePdf(C.probe, ray_dir);
+            const float weight = 0.5f * prd->bsdfPdf / (0.5f * prd->bsdfPdf + 0.5f * skyPdf);
+            prd->radiance += weight * mk3(ProbeEval(C.probe, ProbeDirToUV(ray_dir))) * prd->pathThroughput;
+            prd->sky_added = true;
+        }
         prd->albedo = mk3(0.f);
         prd->normal = mk3(0.f);
         prd->stateFlags |= RAY_STATE_FLAGS_DONE;
@@ -883,6 +907,12 @@ void traceRadiance(const Ctx& C, const f3& ray_origin, const f3& ray_dir, Radian
     prd->direction = bsdfDir;
     prd->origin = P;
     prd->stateFlags |= RAY_STATE_FLAGS_SECONDARY_RAY;
+    if ((C.opt.options & FOVPT_OPT_RUSSIAN_ROULETTE) && prd->depth + 1 >= 2) {     // the //!TODO of :518-520 (opt-in, see include/fovpt.h)
+        const f3 t = prd->pathThroughput;
+        const float q = fmaxf(0.05f, fminf(1.0f, fmaxf(t.x, fmaxf(t.y, t.z))));
+        if (prd->rand.Randf() >= q) prd->rr_kill = true;
+        else prd->pathThroughput = prd->pathThroughput * (1.0f / q);
+    }
 }
 
 inline f3 reinhardToneMap(const f3& color, const float white)       // :126-131
@@ -962,10 +992,15 @@ void raygen(const Ctx& C, uint32_t lx, uint32_t ly)
                 normal += prd.normal;
                 albedo += prd.albedo;
             }
-            if ((prd.stateFlags & RAY_STATE_FLAGS_DONE) || prd.depth >= C.opt.max_depth) break;   // :515
+            if ((prd.stateFlags & RAY_STATE_FLAGS_DONE) || prd.depth >= C.opt.max_depth) {   // :515
+                // FOVPT_OPT_SKY_MISS: an escaped secondary ray's sky radiance counts (depth >= 1 here: secondary)
+                if (prd.sky_added && prd.depth < C.opt.max_depth) indirectLight += prd.radiance;
+                break;
+            }
             if (prd.depth == 0) directLight += prd.radiance;
             else indirectLight += prd.radiance;
             ++prd.depth;
+            if (prd.rr_kill) break;                                                // FOVPT_OPT_RUSSIAN_ROULETTE
             ray_origin = prd.origin;
             ray_direction = prd.direction;
         }
@@ -1117,6 +1152,7 @@ int orc_launch2(void* scene, const fovpt_launch_params* lp, uint32_t width, uint
     if (!scene || !lp || !lp->frame.accum_buffer || !lp->frame.frame_buffer || !lp->probe.data) return FOVPT_E_INVALID;
     if (lp->samples_per_launch == 0) return FOVPT_E_INVALID;     // do{}while(--i) needs spp >= 1 (:448,539)
     Opts o; o.max_depth = max_depth; o.accumulate = accumulate; o.brute = brute; o.nthreads = nthreads; o.write_guides = write_guides;
+    o.options = g_options;
     Counters c;
     launch(*(Scene*)scene, *lp, width, height, o, c);
     if (counters) { counters[0] += c.radiance_rays; counters[1] += c.shadow_rays; counters[2] += c.paths; }
@@ -1134,6 +1170,7 @@ int orc_render(void* scene, fovpt_launch_params* lp, const fovpt_config* cfg, in
     if (lp->frame.size.x == 0) return 0;                                            // :81-82
     fovpt_launch_params& L = *lp;
     int rc;
+    struct OptGuard { int saved; OptGuard(int v) : saved(g_options) { g_options = v; } ~OptGuard() { g_options = saved; } } opt_guard(cfg->options);
     if (cfg->uniform) {                                                             // :85-131 (FOV_OFF)
         L.frame.subframe_index = 0;
         L.frame.factor = mk_u3(1, 1, 1);
@@ -1193,6 +1230,7 @@ void orc_lib_counts(uint64_t* out2, int reset)
     if (out2) { out2[0] = g_lib_radiance; out2[1] = g_lib_shadow; }
     if (reset) { g_lib_radiance = 0; g_lib_shadow = 0; }
 }
+void orc_set_options(int options) { g_options = options; }
 void orc_set_lib_counting(int on) { g_count_lib = on ? 1 : 0; }
 uint64_t orc_occluded_count(int reset)
 {

@@ -355,6 +355,34 @@ def test_packed_gather_plan_pack_unpack(world):
     root.close()
 
 
+@pytest.mark.parametrize("options", [abi.OPT_SKY_MISS, abi.OPT_RUSSIAN_ROULETTE, abi.OPT_SKY_MISS | abi.OPT_RUSSIAN_ROULETTE])
+def test_opt_in_extensions_match_the_oracle(oracle, options):
+    """fovpt_config.options: sky radiance for escaped secondary rays (the MIS counterpart PT_sv5_ carries commented out,
+    deviceProgram.cu:259-269) and Russian roulette (its //!TODO at :518-520).  Neither exists in the reference; the oracle
+    implements them the same way and the GPU must agree with it bit for bit, ray counts included."""
+    size = (192, 108)
+    model, probe = scenes.atrium(12000), scenes.sky_probe(96, 48, seed=3)
+    cfg = cfg_foveated(15, 48, (1, 2, 8), max_depth=6)
+    cfg.options = options
+    r = make_gpu(model, probe, scenes.ATRIUM_CAMERA, size, cfg)
+    r.render()
+    S, F = make_oracle(oracle, model, probe, scenes.ATRIUM_CAMERA, size)
+    cnt = oracle.render(S, F, cfg)
+    assert _eq(r.downloadAccum(), F.accum) and np.array_equal(r.downloadPixels(), F.frame)
+    st = r.stats()
+    assert (st.radiance_rays, st.shadow_rays, st.paths) == (cnt.lib_radiance, cnt.lib_shadow, cnt[2])
+    # and they do something: the plain frame differs
+    plain = cfg.copy()
+    plain.options = 0
+    r.config = plain
+    r.launchParams.frame.subframe_index = 0
+    r.render()
+    assert not _eq(r.downloadAccum(), F.accum)
+    if options & abi.OPT_RUSSIAN_ROULETTE:
+        assert r.stats().radiance_rays - st.radiance_rays > st.radiance_rays          # (stats accumulate: the plain frame traced more)
+    r.close()
+
+
 def test_stereo_asymmetric_frusta(oracle):
     """Two eyes = two cameras and two render() calls per frame (BASELINE.json configs[4]); per-eye off-centre
     frusta enter only through camera U, V, W, so the oracle sees the same LaunchParams."""

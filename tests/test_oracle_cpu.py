@@ -690,3 +690,26 @@ def test_tex2d_contract(oracle):
     assert np.allclose(out[0], [1, 0, 0, 1]) and np.allclose(out[1], [0, 1, 0, 1])
     assert np.allclose(out[2], [0.5, 0.5, 0.5, 1.0])            # centre: equal blend of the four texels
     assert np.allclose(out[3], out[0])                          # wrap addressing
+
+
+def test_opt_in_extensions_behave(oracle):
+    """The two opt-in modes of fovpt_config.options in the oracle (the GPU is held to it in tests/test_gpu_lifecycle.py):
+    Russian roulette is unbiased (the frame mean stays, fewer rays are traced), sky radiance for escaped secondary rays
+    only ever adds light, and options = 0 is the reference's frame."""
+    size = (48, 32)
+    model, probe = scenes.cornell_box(), scenes.sky_probe(64, 32, seed=4)
+    S = oracle.OracleScene(model)
+    means, rays = {}, {}
+    for name, opt in (("plain", 0), ("rr", abi.OPT_RUSSIAN_ROULETTE), ("sky", abi.OPT_SKY_MISS)):
+        F = oracle.OracleFrame(size[0], size[1], oracle.HostProbe(probe), scenes.CORNELL_CAMERA)
+        cfg = abi.Config.reference_default()
+        cfg.uniform, cfg.spp_uniform, cfg.max_depth, cfg.options = 1, 96, 8, opt
+        cnt = oracle.render(S, F, cfg)
+        means[name], rays[name] = F.accum[..., :3].astype(np.float64).mean(), cnt[0]
+        if name == "plain":
+            base = F.accum.copy()
+        elif name == "sky":
+            assert (F.accum[..., :3] >= base[..., :3] - 1e-6).all()
+    assert rays["rr"] < 0.9 * rays["plain"]
+    assert abs(means["rr"] - means["plain"]) < 0.03 * means["plain"]
+    assert means["sky"] > means["plain"] * 1.001

@@ -5,13 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from fovpathtracing_optixcodelatest_amd import abi, renderer, scenes
 
-def run(name, tris, size, cfg, material="app", frames=10, eyes=1, gaze=None):
+def run(name, tris, size, cfg, material="app", frames=10, eyes=1, gaze=None, scene="atrium"):
     W, H = size
-    t = time.time(); model = scenes.atrium(tris, material=material)
+    t = time.time(); model = scenes.atrium(tris, material=material) if scene == "atrium" else scenes.street(tris, material=material)
     r = renderer.SampleRenderer(model)
     r.resize(size)
-    cam = dict(scenes.ATRIUM_CAMERA)
-    r.setProbe(renderer.ProbeData(scenes.ambient_probe(W, H, 2.5)).BuildCDF())
+    cam = dict(scenes.ATRIUM_CAMERA if scene == "atrium" else scenes.STREET_CAMERA)
+    r.setProbe(renderer.ProbeData(scenes.ambient_probe(W, H, 2.5) if scene == "atrium" else scenes.sky_probe(512, 256, seed=5)).BuildCDF())
     r.config = cfg
     r.launchParams.frame.c.x, r.launchParams.frame.c.y = gaze or (W // 2, H // 2)
     setup = time.time() - t
@@ -47,6 +47,8 @@ if "C2" in which: run("C2", 262144, (1920, 1080), uni, material="diffuse")
 if "C3" in which: run("C3", 262144, (1920, 1080), fov(148, 482))
 if "C4" in which: run("C4", 3800000, (2560, 1440), fov(197, 643))
 if "C5" in which: run("C5", 3800000, (2160, 2160), fov(296, 964, depth=8), eyes=2, frames=5)
+if "C4S" in which: run("C4-street", 3800000, (2560, 1440), fov(197, 643), scene="street")
+if "C5S" in which: run("C5-street", 3800000, (2160, 2160), fov(296, 964, depth=8), eyes=2, frames=5, scene="street")
 if "REF" in which:   # the reference's own shipped settings: 74/241, 8/16/32 spp
     c = abi.Config.reference_default(); run("REF-shipped", 262144, (1920, 1080), c)
 if "U4" in which:    # FOV_OFF as shipped: uniform 4 spp
