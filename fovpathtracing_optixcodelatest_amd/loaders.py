@@ -677,8 +677,31 @@ def load_gltf(gltf_file: str) -> Model:
     import base64
     import json
     base = os.path.dirname(os.path.abspath(gltf_file))
-    with open(gltf_file, "r") as f:
-        g = json.load(f)
+    with open(gltf_file, "rb") as f:
+        raw = f.read()
+    glb_bin = None
+    if raw[:4] == b"glTF":
+        # binary container (.glb; tinygltf's LoadBinaryFromFile -- the reference only ever calls LoadASCIIFromFile,
+        # sutil/Scene.cpp:265, so this is glue beyond it): 12-byte header {magic, version 2, length}, then chunks
+        # {length, type, data}: the first is JSON, an optional second one BIN, which serves a buffer without `uri`
+        import struct
+        magic, version, total = struct.unpack_from("<4sII", raw, 0)
+        if version != 2 or total > len(raw):
+            raise ValueError("glb: unsupported version %d or truncated file" % version)
+        pos, chunks = 12, []
+        while pos + 8 <= total:
+            clen, ctype = struct.unpack_from("<II", raw, pos)
+            chunks.append((ctype, raw[pos + 8:pos + 8 + clen]))
+            pos += 8 + clen + ((-clen) % 4)
+        if not chunks or chunks[0][0] != 0x4E4F534A:
+            raise ValueError("glb: the first chunk is not JSON")
+        g = json.loads(chunks[0][1].decode("utf-8"))
+        for ctype, data in chunks[1:]:
+            if ctype == 0x004E4942:
+                glb_bin = data
+                break
+    else:
+        g = json.loads(raw.decode("utf-8"))
 
     def read_uri(uri: str) -> bytes:
         if uri.startswith("data:"):
@@ -686,7 +709,14 @@ def load_gltf(gltf_file: str) -> Model:
         with open(os.path.join(base, uri), "rb") as fh:
             return fh.read()
 
-    buffers = [read_uri(b["uri"]) for b in g.get("buffers", [])]
+    buffers = []
+    for k, b in enumerate(g.get("buffers", [])):
+        if "uri" in b:
+            buffers.append(read_uri(b["uri"]))
+        elif k == 0 and glb_bin is not None:
+            buffers.append(glb_bin)
+        else:
+            raise ValueError("gltf: buffer %d has no uri" % k)
 
     def accessor(idx: int) -> np.ndarray:
         a = g["accessors"][idx]

@@ -226,6 +226,30 @@ def test_gltf_traversal_transforms_and_materials(tmp_path):
     assert b.material.transmission == d.transmission and b.material.specular == d.specular and b.material.eta == d.eta
 
 
+def test_glb_container_gives_the_same_model(tmp_path):
+    """.glb = header + JSON chunk + BIN chunk; buffer 0 without a uri is the BIN chunk.  Same scene as the .gltf fixture."""
+    import json
+    import struct
+    path, _ = _gltf_fixture(tmp_path)
+    want = loaders.load_gltf(path)
+    g = json.load(open(path))
+    blob = (tmp_path / "geo.bin").read_bytes()
+    del g["buffers"][0]["uri"]                                               # served by the BIN chunk
+    js = json.dumps(g).encode()
+    js += b" " * ((-len(js)) % 4)
+    bn = blob + b"\0" * ((-len(blob)) % 4)
+    glb = struct.pack("<4sII", b"glTF", 2, 12 + 8 + len(js) + 8 + len(bn)) + struct.pack("<II", len(js), 0x4E4F534A) + js \
+        + struct.pack("<II", len(bn), 0x004E4942) + bn
+    (tmp_path / "s.glb").write_bytes(glb)
+    got = loaders.load_gltf(str(tmp_path / "s.glb"))
+    assert len(got.meshes) == len(want.meshes)
+    for a, b in zip(got.meshes, want.meshes):
+        assert np.array_equal(a.vertex, b.vertex) and np.array_equal(a.index, b.index) and bytes(a.material) == bytes(b.material)
+    (tmp_path / "bad.glb").write_bytes(struct.pack("<4sII", b"glTF", 1, 12))
+    with pytest.raises(ValueError):
+        loaders.load_gltf(str(tmp_path / "bad.glb"))
+
+
 def test_gltf_model_packs_for_the_c_abi(tmp_path):
     from fovpathtracing_optixcodelatest_amd import scenes
     path, _ = _gltf_fixture(tmp_path)
