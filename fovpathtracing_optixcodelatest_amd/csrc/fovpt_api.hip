@@ -485,7 +485,7 @@ int fovpt_create(fovpt_ctx** out, int device)
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
     c->grid = c->num_cus * 8;                 // 8 blocks of 256 = 32 waves per CU, grid-stride over the queues; a multiple of FOVPT_SHARDS
     c->grid_shadow = c->num_cus * 6;          // occlusion launches (measured best of 2..8 with per-wave ray pools)
-    if (const char* g = getenv("FOVPT_GRID")) { const int v = atoi(g); if (v > 0 && v <= 16) c->grid = c->num_cus * v; }                 // tuning: blocks per CU
+    if (const char* g = getenv("FOVPT_GRID")) { const int v = atoi(g); if (v > 0 && v <= 64) c->grid = c->num_cus * v; }                 // tuning: blocks per CU
     if (const char* g = getenv("FOVPT_GRID_SHADOW")) { const int v = atoi(g); if (v > 0 && v <= 16) c->grid_shadow = c->num_cus * v; }   // tuning: blocks per CU
     c->grid = (c->grid + FOVPT_SHARDS - 1) / FOVPT_SHARDS * FOVPT_SHARDS;      // shard_capacity() relies on it
     // the shading kernel holds 4 waves per SIMD (104 VGPRs) = 4 blocks per CU; twice the resident number of blocks is

@@ -1513,16 +1513,23 @@ __global__ void k_cdf_rows(int w, int h, const float4* __restrict__ data, float*
     }
     row_total[j] = totalWeightX;
 }
+// (the running sum over the rows is sequential by contract -- one thread; the two divisions per row are not)
 __global__ void k_cdf_cols(int h, const float* __restrict__ row_total, float* __restrict__ pdfY, float* __restrict__ cdfY)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    float totalWeightY = 0.0f;
-    for (int j = 0; j < h; ++j) {
-        totalWeightY += row_total[j];
-        pdfY[j] = row_total[j];
-        cdfY[j] = totalWeightY;
+    __shared__ float s_total;
+    if (blockIdx.x != 0) return;
+    if (threadIdx.x == 0) {
+        float totalWeightY = 0.0f;
+        for (int j = 0; j < h; ++j) {
+            totalWeightY += row_total[j];
+            pdfY[j] = row_total[j];
+            cdfY[j] = totalWeightY;
+        }
+        s_total = totalWeightY;
     }
-    for (int j = 0; j < h; ++j) {
+    __syncthreads();
+    const float totalWeightY = s_total;
+    for (int j = (int)threadIdx.x; j < h; j += (int)blockDim.x) {
         cdfY[j] /= totalWeightY;
         pdfY[j] /= totalWeightY;
     }
@@ -1607,7 +1614,7 @@ void fovpt_launch_build_guide(hipStream_t st, const float* cdf, int n, int segme
 void fovpt_launch_build_cdf(hipStream_t st, int w, int h, const float4* data, float* pdfX, float* cdfX, float* pdfY, float* cdfY, float* row_total)
 {
     hipLaunchKernelGGL(k_cdf_rows, dim3((h + 63) / 64), dim3(64), 0, st, w, h, data, pdfX, cdfX, row_total);
-    hipLaunchKernelGGL(k_cdf_cols, dim3(1), dim3(64), 0, st, h, row_total, pdfY, cdfY);
+    hipLaunchKernelGGL(k_cdf_cols, dim3(1), dim3(256), 0, st, h, row_total, pdfY, cdfY);
 }
 void fovpt_launch_math(hipStream_t st, int op, const float* a, const float* b, float* out, size_t n)
 {
