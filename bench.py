@@ -99,7 +99,7 @@ def run_counter_passes(timeout_s=150):
         disp = {}
         for f in files:
             for row in csv.DictReader(open(f)):
-                m = re.search(r"\b(k_[a-z_0-9]+)\s*\(", row["Kernel_Name"])
+                m = re.search(r"\b(k_[a-z_0-9]+)(?:<[^>]*>)?\s*\(", row["Kernel_Name"])
                 if not m:
                     continue
                 dd = disp.setdefault((f, row["Dispatch_Id"]), {"k": m.group(1)})

@@ -488,6 +488,7 @@ int fovpt_create(fovpt_ctx** out, int device)
     if (const char* g = getenv("FOVPT_GRID")) { const int v = atoi(g); if (v > 0 && v <= 64) c->grid = c->num_cus * v; }                 // tuning: blocks per CU
     if (const char* g = getenv("FOVPT_GRID_SHADOW")) { const int v = atoi(g); if (v > 0 && v <= 16) c->grid_shadow = c->num_cus * v; }   // tuning: blocks per CU
     c->grid = (c->grid + FOVPT_SHARDS - 1) / FOVPT_SHARDS * FOVPT_SHARDS;      // shard_capacity() relies on it
+    c->grid_shadow = (c->grid_shadow + FOVPT_SHARDS - 1) / FOVPT_SHARDS * FOVPT_SHARDS;      // the work fetch of k_traverse relies on equal shard groups
     // the shading kernel holds 4 waves per SIMD (104 VGPRs) = 4 blocks per CU; twice the resident number of blocks is
     // measured best (blocks per CU 2 / 3 / 4 / 6 / 8: shading 0.307 / 0.274 / 0.261 / 0.263 / 0.244 ms per C3 frame)
     c->grid_shade = c->grid;

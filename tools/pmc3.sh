@@ -12,7 +12,7 @@ import csv, re, collections
 rows=list(csv.DictReader(open("$OUT/p_counter_collection.csv")))
 by=collections.OrderedDict()
 for r in rows:
-    m=re.search(r"\b(k_[a-z_0-9]+)\s*\(", r["Kernel_Name"])
+    m=re.search(r"\b(k_[a-z_0-9]+)(?:<[^>]*>)?\s*\(", r["Kernel_Name"])
     if not m: continue
     d=by.setdefault(int(r["Dispatch_Id"]), {"k":m.group(1), "dur":(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1000})
     d[r["Counter_Name"]]=float(r["Counter_Value"])

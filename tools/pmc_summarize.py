@@ -24,7 +24,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         for row in csv.DictReader(open(f)):
             if row.get("Counter_Name") != counter:
                 continue
-            m = re.search(r"\b(k_[a-z_0-9]+)\s*\(", row["Kernel_Name"])
+            m = re.search(r"\b(k_[a-z_0-9]+)(?:<[^>]*>)?\s*\(", row["Kernel_Name"])
             name = m.group(1) if m else row["Kernel_Name"][:40]
             acc[name][0] += float(row["Counter_Value"])
             acc[name][1] += 1
