@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc2_$TAG
 mkdir -p $OUT
-rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $OUT -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-counters --no-variants > $OUT/stdout.log 2>&1 || { tail -5 $OUT/stdout.log; exit 1; }
+timeout -k 10 200 rocprofv3 --pmc $CNT --kernel-trace --output-format csv -d $OUT -o p -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-counters --no-variants > $OUT/stdout.log 2>&1 || { tail -5 $OUT/stdout.log; exit 1; }
 python3 - <<PY
 import csv, re, collections
 acc=collections.defaultdict(lambda: collections.defaultdict(float)); n=collections.Counter()
