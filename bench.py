@@ -76,7 +76,7 @@ PMC_PASSES = {
 }
 
 
-def run_counter_passes(timeout_s=150):
+def run_counter_passes(timeout_s=90):
     """-> ({kernel: {counter: mean per dispatch, "launches": n, "dur_us": mean serialised duration}}, note)"""
     exe = shutil.which("rocprofv3")
     if not exe:
