@@ -71,7 +71,7 @@ struct fovpt_ctx {
     std::vector<void*> tex_pixels;
     uint32_t num_tris = 0, any_catcher = 0;
     // probe
-    DevBuf pr_data, pr_pdfx, pr_cdfx, pr_pdfy, pr_cdfy, pr_guidex, pr_guidey;
+    DevBuf pr_data, pr_pdfx, pr_cdfx, pr_pdfy, pr_cdfy, pr_guidex, pr_guidey, pr_rec;
     bool guide_ok = false;
     int guide_w = 0, guide_h = 0;
     bool rows_identical = false;           // every row of data / pdfX / cdfX equals row 0 bit for bit
@@ -314,6 +314,9 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
                            && lp->probe.width == c->guide_w && lp->probe.height == c->guide_h;
     fd.guide_x = own_probe ? (const uint32_t*)c->pr_guidex.p : nullptr;
     fd.guide_y = own_probe ? (const uint32_t*)c->pr_guidey.p : nullptr;
+    // (a probe whose rows are all alike is served from ONE row of the split arrays, which stays in L1; its 32-byte records would not)
+    fd.probe_rec = (own_probe && !c->rows_identical && lp->probe.data == (fovpt_float4*)c->pr_data.p && lp->probe.pdfValuesX == (float*)c->pr_pdfx.p)
+                   ? (const float4*)c->pr_rec.p : nullptr;
     fd.probe_row_mul = (c->rows_identical && lp->probe.data == (fovpt_float4*)c->pr_data.p && lp->probe.pdfValuesX == (float*)c->pr_pdfx.p
                         && lp->probe.cdfValuesX == (float*)c->pr_cdfx.p && lp->probe.width == c->guide_w && lp->probe.height == c->guide_h) ? 0 : 1;
     fd.accum = lp->frame.accum_buffer;
@@ -529,7 +532,7 @@ void fovpt_destroy(fovpt_ctx* c)
         for (DevBuf* b : S.all()) b->release();
     }
     free_scene(c);
-    DevBuf* bufs[] = {&c->tri_tc, &c->meshes, &c->textures, &c->pr_data, &c->pr_pdfx, &c->pr_cdfx, &c->pr_pdfy, &c->pr_cdfy, &c->pr_guidex, &c->pr_guidey,
+    DevBuf* bufs[] = {&c->tri_tc, &c->meshes, &c->textures, &c->pr_data, &c->pr_pdfx, &c->pr_cdfx, &c->pr_pdfy, &c->pr_cdfy, &c->pr_guidex, &c->pr_guidey, &c->pr_rec,
                       &c->fb_frame, &c->fb_accum, &c->fb_color, &c->fb_normal, &c->fb_albedo, &c->accum_before,
                       &c->plan_owner, &c->plan_blocks, &c->plan_total, &c->plan_base, &c->plan_idx};
     for (DevBuf* b : bufs) b->release();
@@ -683,6 +686,8 @@ int fovpt_set_probe(fovpt_ctx* c, int width, int height, const fovpt_float4* dat
         HIPCHK(c, c->pr_guidey.reserve((size_t)(height + 2) * 4));
         fovpt_launch_build_guide(c->stream, (const float*)c->pr_cdfx.p, width, height, (uint32_t*)c->pr_guidex.p);
         fovpt_launch_build_guide(c->stream, (const float*)c->pr_cdfy.p, height, 1, (uint32_t*)c->pr_guidey.p);
+        HIPCHK(c, c->pr_rec.reserve(n * 32));
+        fovpt_launch_probe_records(c->stream, n, (const float*)c->pr_cdfx.p, (const float*)c->pr_pdfx.p, (const float4*)c->pr_data.p, (float4*)c->pr_rec.p);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->guide_ok = true;
     }
@@ -734,6 +739,8 @@ int fovpt_set_probe_data(fovpt_ctx* c, int width, int height, const fovpt_float4
         HIPCHK(c, c->pr_guidey.reserve((size_t)(height + 2) * 4));
         fovpt_launch_build_guide(c->stream, (const float*)c->pr_cdfx.p, width, height, (uint32_t*)c->pr_guidex.p);
         fovpt_launch_build_guide(c->stream, (const float*)c->pr_cdfy.p, height, 1, (uint32_t*)c->pr_guidey.p);
+        HIPCHK(c, c->pr_rec.reserve(n * 32));
+        fovpt_launch_probe_records(c->stream, n, (const float*)c->pr_cdfx.p, (const float*)c->pr_pdfx.p, (const float4*)c->pr_data.p, (float4*)c->pr_rec.p);
         HIPCHK(c, hipStreamSynchronize(c->stream));
         c->guide_ok = true;
     }

@@ -96,6 +96,7 @@ struct FrameDev {
     fovpt_probe probe;            // device pointers
     const uint32_t* guide_x;      // lower_bound guide tables for probe.cdfValuesX / Y, or null
     const uint32_t* guide_y;
+    const float4* probe_rec;      // packed {cdfX, pdfX, r, g, b} records per texel (two float4), or null
     int32_t probe_row_mul;        // 0 when all probe rows are identical (constant ambient probe), else 1
     fovpt_float4* accum;
     const fovpt_float4* accum_prev;   // what accumulate mode blends with: accum itself, or its copy from before a chunked launch
@@ -194,5 +195,6 @@ void fovpt_launch_gather_pack(hipStream_t st, uint32_t n, const uint32_t* idx, c
 void fovpt_launch_gather_unpack(hipStream_t st, int world, uint32_t stride, uint32_t total, const uint32_t* base, const uint32_t* idx,
                                 const uint32_t* gathered, uint32_t* frame);
 void fovpt_launch_build_guide(hipStream_t st, const float* cdf, int n, int segments, uint32_t* guide);
+void fovpt_launch_probe_records(hipStream_t st, size_t n, const float* cdfX, const float* pdfX, const float4* data, float4* rec);
 void fovpt_launch_build_cdf(hipStream_t st, int w, int h, const float4* data, float* pdfX, float* cdfX, float* pdfY, float* cdfY, float* row_total);
 void fovpt_launch_math(hipStream_t st, int op, const float* a, const float* b, float* out, size_t n);
