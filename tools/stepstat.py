@@ -6,11 +6,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from fovpathtracing_optixcodelatest_amd import abi, renderer, scenes, lib
 W, H = 1920, 1080
-model = scenes.atrium(262144)
+street = os.environ.get("FOVPT_SCENE") == "street"
+model = scenes.street(int(os.environ.get("FOVPT_TRIS", "3800000"))) if street else scenes.atrium(int(os.environ.get("FOVPT_TRIS", "262144")))
 r = renderer.SampleRenderer(model); r.resize((W, H))
-cam = scenes.ATRIUM_CAMERA
+cam = scenes.STREET_CAMERA if street else scenes.ATRIUM_CAMERA
 r.setCamera(renderer.Camera(cam["eye"], cam["lookat"], cam["up"], cam["fovy"], W / H))
-r.setProbe(renderer.ProbeData(scenes.ambient_probe(W, H, 2.5)).BuildCDF())
+r.setProbe(renderer.ProbeData(scenes.sky_probe(512, 256, seed=5) if street else scenes.ambient_probe(W, H, 2.5)).BuildCDF())
 cfg = abi.Config.reference_default(); cfg.r_inner, cfg.r_outer = 148, 482
 cfg.spp_periphery, cfg.spp_middle, cfg.spp_fovea = 1, 2, 8
 cfg.max_depth = int(os.environ.get("FOVPT_DEPTH", "4"))
