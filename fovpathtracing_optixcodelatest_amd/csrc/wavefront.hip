@@ -1166,24 +1166,27 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
                         } else {
                             *cell = f4(rad_occ, 0.f);
                         }
-                        const V3 f = bsdf_eval(mat, albedo, view, N, wo, bsdfDir);                  // :714
-                        if (dot(bsdfDir, N) <= 0.0f) rayEta = outEta;                      // :717-721
-                        thr = thr * div_vs(f * fabsf(dot(N, bsdfDir)), bsdfPdf);           // :724
                         flags |= FLAG_SECONDARY;
                         depth += 1;                                                        // :529
                         // The reference traces once more at depth == max_depth and throws the result
                         // away (:515).  Without a shadow catcher in the scene that segment cannot
-                        // change anything (alpha is already 1), so it is not traced.
-                        bool rr_kill = false;
-                        if (EXTRA && (fd.options & FOVPT_OPT_RUSSIAN_ROULETTE) && depth >= 2) {   // the //!TODO of :518-520, see include/fovpt.h
-                            const float q = fmaxf(0.05f, fminf(1.0f, fmaxf(thr.x, fmaxf(thr.y, thr.z))));
-                            if (rng.randf() >= q) rr_kill = true;
-                            else thr = thr * (1.0f / q);
-                        }
-                        if (!rr_kill && (depth < fd.max_depth || sc.any_catcher)) {
-                            next_o = P; next_d = bsdfDir; next_pdf = bsdfPdf;
-                            ps.thr[slot] = f4(thr, rayEta);
-                            want_next = true;
+                        // change anything (alpha is already 1), so it is not traced -- and then nothing reads the
+                        // throughput, the medium or the random numbers of this path any more (:714-724 skipped).
+                        if (depth < fd.max_depth || sc.any_catcher) {
+                            const V3 f = bsdf_eval(mat, albedo, view, N, wo, bsdfDir);              // :714
+                            if (dot(bsdfDir, N) <= 0.0f) rayEta = outEta;                  // :717-721
+                            thr = thr * div_vs(f * fabsf(dot(N, bsdfDir)), bsdfPdf);       // :724
+                            bool rr_kill = false;
+                            if (EXTRA && (fd.options & FOVPT_OPT_RUSSIAN_ROULETTE) && depth >= 2) {   // the //!TODO of :518-520, see include/fovpt.h
+                                const float q = fmaxf(0.05f, fminf(1.0f, fmaxf(thr.x, fmaxf(thr.y, thr.z))));
+                                if (rng.randf() >= q) rr_kill = true;
+                                else thr = thr * (1.0f / q);
+                            }
+                            if (!rr_kill) {
+                                next_o = P; next_d = bsdfDir; next_pdf = bsdfPdf;
+                                ps.thr[slot] = f4(thr, rayEta);
+                                want_next = true;
+                            }
                         }
                     }
                     rs.x = rng.s1; rs.y = rng.s2;
