@@ -633,10 +633,42 @@ def load_hdr(path: str) -> np.ndarray:
     return _rgbe_to_float4(rows)
 
 
+def ldr_to_float4(rgba8: np.ndarray) -> np.ndarray:
+    """What stbi_loadf(file, ..., 4) makes of an 8-bit image (stb_image's stbi__ldr_to_hdr with its default gamma 2.2 and
+    scale 1): colour channels powf(c / 255, 2.2), alpha c / 255.  (libm's powf, so equal to stb's floats up to the last
+    bit of a vectorised powf.)"""
+    c = rgba8.astype(np.float32) / np.float32(255.0)
+    out = np.empty(rgba8.shape[:2] + (4,), np.float32)
+    out[..., :3] = np.power(c[..., :3], np.float32(2.2), dtype=np.float32)
+    out[..., 3] = c[..., 3]
+    return out
+
+
+def load_probe_texels(path: str) -> np.ndarray:
+    """The float4 texels loadProbe hands to BuildCDF: stbi_loadf reads Radiance .hdr files as they are and any 8-bit
+    format it knows through stbi__ldr_to_hdr.  (The comment at main.cpp:220 says .exr is readable too; stb_image has no
+    EXR reader, stbi_loadf returns NULL for one.)"""
+    with open(path, "rb") as f:
+        head = f.read(16)
+    if head.startswith(b"#?RADIANCE") or head.startswith(b"#?RGBE"):
+        return load_hdr(path)
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:8] == b"\x89PNG\r\n\x1a\n":
+        rgba = decode_png(data)
+    elif data[:2] == b"P6":
+        rgba = _decode_ppm(data)
+    elif path.lower().endswith(".tga"):
+        rgba = decode_tga(data)
+    else:
+        raise ValueError("%s: not an image stbi_loadf can read here (.hdr, .png, .ppm, .tga)" % path)
+    return ldr_to_float4(rgba)
+
+
 def load_probe(hdr_file: str):
     """loadProbe (PT_sv5_/main.cpp:160-171): texels from the file, then ProbeData::BuildCDF."""
     from .renderer import ProbeData
-    return ProbeData(load_hdr(hdr_file)).BuildCDF()
+    return ProbeData(load_probe_texels(hdr_file)).BuildCDF()
 
 
 # ------------------------------------------------------------------------------------------

@@ -153,7 +153,7 @@ def main():
             out8 = np.zeros((hh.value, w.value, 4), np.uint8)
             L.ref_stbi_load(os.path.join(d, name).encode(), C.byref(w), C.byref(hh), _p(out8), C.c_size_t(out8.size))
             lb["stbi_load:" + name] = out8
-        for name in ("probe_rle.hdr", "probe_flat.hdr"):
+        for name in ("probe_rle.hdr", "probe_flat.hdr", "rgb8.png", "rgba16_adam7.png", "tex.ppm"):
             w, hh = C.c_int(0), C.c_int(0)
             assert L.ref_stbi_loadf(os.path.join(d, name).encode(), C.byref(w), C.byref(hh), None, C.c_size_t(0)), name
             outf = np.zeros((hh.value, w.value, 4), np.float32)
