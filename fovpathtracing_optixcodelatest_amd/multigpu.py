@@ -24,11 +24,12 @@ def launch_owner(pass_index, lx, ly, world, tile_w=8, tile_h=4):
     return ((lx // tile_w) + 3 * (ly // tile_h) + pass_index) % world
 
 
-def gather_frame(frame: torch.Tensor, dst: int = 0, group=None, async_op: bool = False):
+def gather_frame(frame: torch.Tensor, dst: int = 0, group=None, async_op: bool = False, force_collective: bool = False):
     """Sum-reduce the per-rank frames (int32 rgba8 words, or float accum) onto rank `dst`.
     With async_op=True returns the work handle (None when there is nothing to do) so the caller can
-    overlap the gather of frame k with the rendering of frame k+1."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    overlap the gather of frame k with the rendering of frame k+1.  force_collective: issue the collective even
+    in a group of one (tests: the RCCL code path on a one-GPU box)."""
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force_collective):
         return None if async_op else frame
     work = dist.reduce(frame, dst=dst, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
     return work if async_op else frame
@@ -67,8 +68,9 @@ class PackedGather:
     All device work (pack, unpack) runs on the library's frame-completion stream (fovpt_stream()); issue `gather`
     under `torch.cuda.stream(ExternalStream(r.stream))` so the collective is ordered behind the pack on the device."""
 
-    def __init__(self, r, device, dst=0, group=None, nbuffers=2):
+    def __init__(self, r, device, dst=0, group=None, nbuffers=2, force_collective=False):
         self.r, self.device, self.dst, self.group = r, device, dst, group
+        self.force_collective = force_collective and dist.is_initialized()      # tests: a group of one still calls RCCL
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.nbuffers = nbuffers
@@ -92,7 +94,7 @@ class PackedGather:
     def gather(self, frame: torch.Tensor, k: int = 0, async_op: bool = False):
         """pack + gather of buffer set k.  Returns the work handle (async) or None; call finish() afterwards on dst."""
         self.r.gather_pack(frame.data_ptr(), self.packed[k].data_ptr())
-        if self.world == 1:
+        if self.world == 1 and not self.force_collective:
             if self.rank == self.dst:
                 self.gathered[k][0].copy_(self.packed[k])
             return None

@@ -195,6 +195,80 @@ def test_bench_two_rank_rehearsal_gathers_the_full_frame():
     assert out["config"]["rays_per_frame"] > 3.0e6        # both ranks' rays are counted
 
 
+_RCCL_ONE_RANK = r"""
+import os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.path.join(os.environ["FOVPT_ROOT"], "tests"))
+from fovpathtracing_optixcodelatest_amd import multigpu, scenes
+from common import cfg_foveated, make_gpu
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl"
+size = (320, 200)
+cfg = cfg_foveated(24, 80, (1, 2, 6))
+r = make_gpu(scenes.atrium(8000), scenes.sky_probe(), scenes.ATRIUM_CAMERA, size, cfg, gaze=(250, 60))
+r.render()
+want = torch.from_numpy(r.downloadPixels().reshape(-1).view(np.int32).copy())
+pg = multigpu.PackedGather(r, dev, dst=0, nbuffers=2, force_collective=True)
+counts = pg.plan()
+frames = [torch.zeros(size[0] * size[1], dtype=torch.int32, device="cuda") for _ in range(2)]
+ext = torch.cuda.ExternalStream(r.stream, device=dev)
+works, done = [], []
+with torch.cuda.stream(ext):
+    for k in range(4):                                   # bench.py's loop: render, pack + RCCL gather, retire two frames later
+        b = k % 2
+        if k >= 2:
+            works[k - 2].wait()
+            pg.finish(frames[b], b)
+            done.append(frames[b].clone())               # enqueued behind the unpack; compared after the loop
+            frames[b].zero_()
+        r.launchParams.frame.subframe_index = 0
+        r.launchParams.frame.frame_buffer = frames[b].data_ptr()
+        r.render_async()
+        w = pg.gather(frames[b], b, async_op=True)
+        assert w is not None                             # a real collective, not the group-of-one shortcut
+        works.append(w)
+        frames[b].zero_()                                # only the gathered buffers carry the pixels from here on
+    for k in (2, 3):
+        works[k].wait()
+        pg.finish(frames[k % 2], k % 2)
+    # the older full-frame reduce through RCCL as well
+    f = want.to("cuda").clone()
+    w = multigpu.gather_frame(f, dst=0, async_op=True, force_collective=True)
+    w.wait()
+ext.synchronize()
+torch.cuda.synchronize()
+for k, d in enumerate(done + frames):
+    assert torch.equal(d.cpu(), want), "frame %d" % k
+assert torch.equal(f.cpu(), want)
+r.close()
+dist.destroy_process_group()
+print("RCCL-ONE-RANK-OK", counts)
+"""
+
+
+def test_rccl_group_of_one_runs_the_packed_gather_on_the_library_stream():
+    """The collective half of the multi-GPU gather on the real backend: RCCL is initialised (a group of one -- this box has
+    one GPU, and RCCL refuses two ranks per device), and bench.py's loop shape -- render, HIP pack, `dist.gather` under
+    torch.cuda.ExternalStream(fovpt_stream()), wait, HIP unpack two frames later -- reproduces the frame bit for bit with no host
+    synchronisation in between."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), FOVPT_ROOT=root, HSA_ENABLE_IPC_MODE_LEGACY="0",
+               PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    res = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK], capture_output=True, text=True, env=env, timeout=300, cwd=root)
+    assert res.returncode == 0 and "RCCL-ONE-RANK-OK" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+
+
 @pytest.mark.parametrize("uniform", [False, True])
 def test_chunked_jobs_for_large_launches(oracle, monkeypatch, uniform):
     """Launches whose sample slots exceed the per-job budget (the reference's own 3840x2160 x 32 spp FOV_OFF
