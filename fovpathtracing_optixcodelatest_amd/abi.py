@@ -127,6 +127,15 @@ class MeshDesc(C.Structure):
     ]
 
 
+class ModelMesh(C.Structure):
+    """fovpt_model_mesh: one TriangleMesh of a model loaded by fovpt_model_load_obj (arrays owned by the model)."""
+    _fields_ = [
+        ("vertex", C.c_void_p), ("normal", C.c_void_p), ("texcoord", C.c_void_p), ("index", C.c_void_p),
+        ("num_vertices", C.c_uint32), ("num_normals", C.c_uint32), ("num_texcoords", C.c_uint32), ("num_triangles", C.c_uint32),
+        ("material", Material), ("diffuse_texture_id", C.c_int32),
+    ]
+
+
 class TextureDesc(C.Structure):
     _fields_ = [("pixel", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32)]
 

@@ -35,6 +35,9 @@ struct EventPair { hipEvent_t a, b; int kind; };   // kind: 0 gen, 1 trace, 2 sh
 
 }  // namespace
 
+// for the context-free entry points of other translation units (model_loader.cpp): the text fovpt_last_error(NULL) returns
+void fovpt_internal_set_error(const char* text) { g_create_error = text ? text : ""; }
+
 // Shadow-queue buffers per state set: bounce it writes buffer it % FOVPT_NSQ, so with max_depth <= FOVPT_NSQ the
 // main chain never has to wait for an occlusion launch inside a job.
 #define FOVPT_NSQ 4

@@ -1,0 +1,586 @@
+// model_loader.cpp -- host-side scene ingestion behind the C ABI (fovpt_model_*, include/fovpt.h): what a C++ caller
+// of the reference gets from loadOBJ (PT_sv5_/Model.cpp:138-217), addVertex (:49-82) and loadTexture (:84-136), i.e.
+// from the vendored tinyobjloader 2.0.0-rc (support/tinyobjloader, LoadObj with triangulate = true) and stb_image
+// (stbi_load(..., STBI_rgb_alpha)).  Written from the behaviour, not from their text; pinned to the reference's own
+// output by tests/test_ref_pin_cpu.py (tests/golden/ref_loaders.npz and, where oracle/_ref exists, seeded random OBJ
+// files through both).  Plain host C++: no HIP, no GPU needed.
+//
+// What is reproduced (and tested):
+//   * OBJ: v / vn / vt (one or two coordinates) / f with every corner syntax and negative (relative) indices,
+//     o and g starting a new shape, usemtl, mtllib (several files), polygons triangulated by ear clipping in
+//     binary32 on the projection tinyobj picks; a convex planar quad becomes the fan (0,1,2) (0,2,3)
+//   * MTL: newmtl, Kd (absent: 0 0 0), Ke, map_Kd with options before the file name
+//   * one TriangleMesh per (shape, material id) in ascending id order; vertices de-duplicated per SHAPE by their
+//     (v, vn, vt) triple -- the reference's map lives per shape, so a corner first used under an earlier material
+//     keeps the index it got in THAT mesh (a quirk of the reference, kept); textures are looked up per shape too,
+//     so a file named by two shapes is loaded twice
+//   * textures: PNG (all colour types and bit depths, tRNS, Adam7) and binary PPM, as stbi_load returns them with four
+//     channels, then mirrored along y (:117-126).  Anything else counts as "could not load": id -1 (:129-131).
+#include <zlib.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <memory>
+#include <set>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/fovpt.h"
+
+void fovpt_internal_set_error(const char* text);      // fovpt_api.hip: what fovpt_last_error(NULL) returns
+
+namespace {
+
+struct Corner {                                        // tinyobj::index_t in the reference's comparison order (:30-44)
+    int v, vn, vt;
+    bool operator<(const Corner& o) const
+    {
+        if (v != o.v) return v < o.v;
+        if (vn != o.vn) return vn < o.vn;
+        return vt < o.vt;
+    }
+};
+struct F3 { float x, y, z; };
+struct F2 { float x, y; };
+
+struct MtlRec {
+    bool has_kd = false;
+    float kd[3] = {0.f, 0.f, 0.f}, ke[3] = {0.f, 0.f, 0.f};
+    std::string map_kd;
+};
+
+struct Image { int w = 0, h = 0; std::vector<uint32_t> px; };        // rgba8 words, row 0 first
+
+std::vector<std::string> split_ws(const std::string& line)
+{
+    std::vector<std::string> t;
+    const size_t end = std::min(line.find('#'), line.size());
+    size_t i = 0;
+    while (i < end) {
+        while (i < end && isspace((unsigned char)line[i])) i++;
+        size_t j = i;
+        while (j < end && !isspace((unsigned char)line[j])) j++;
+        if (j > i) t.emplace_back(line, i, j - i);
+        i = j;
+    }
+    return t;
+}
+std::string join_from(const std::vector<std::string>& t, size_t first)
+{
+    std::string s;
+    for (size_t k = first; k < t.size(); k++) { if (k > first) s += ' '; s += t[k]; }
+    return s;
+}
+float to_f(const std::string& s) { return (float)strtod(s.c_str(), nullptr); }     // decimal -> binary64 -> binary32
+
+bool read_lines(const std::string& path, std::vector<std::string>& lines)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    std::string l;
+    while (std::getline(f, l)) { if (!l.empty() && l.back() == '\r') l.pop_back(); lines.push_back(l); }
+    return true;
+}
+
+void parse_mtl(const std::string& path, std::vector<std::pair<std::string, MtlRec>>& out)
+{
+    std::vector<std::string> lines;
+    if (!read_lines(path, lines)) return;
+    std::map<std::string, size_t> seen;               // a name defined twice in one file: the later record replaces the earlier
+    MtlRec* cur = nullptr;
+    for (const std::string& line : lines) {
+        const std::vector<std::string> t = split_ws(line);
+        if (t.empty()) continue;
+        const std::string& k = t[0];
+        if (k == "newmtl") {
+            const std::string name = join_from(t, 1);
+            auto it = seen.find(name);
+            if (it == seen.end()) { seen[name] = out.size(); out.emplace_back(name, MtlRec()); cur = &out.back().second; }
+            else { out[it->second].second = MtlRec(); cur = &out[it->second].second; }
+        } else if (!cur) {
+            continue;
+        } else if (k == "Kd" && t.size() >= 4) {
+            cur->has_kd = true;
+            for (int a = 0; a < 3; a++) cur->kd[a] = to_f(t[1 + a]);
+        } else if (k == "Ke" && t.size() >= 4) {
+            for (int a = 0; a < 3; a++) cur->ke[a] = to_f(t[1 + a]);
+        } else if (k == "map_Kd" && t.size() >= 2) {
+            cur->map_kd = t.back();                   // options (-s, -o, ...) precede the file name
+        }
+    }
+}
+
+// 'v', 'v/vt', 'v//vn', 'v/vt/vn' -> zero-based indices, -1 for absent; negative = relative to the end so far
+bool parse_corner(const std::string& tok, int nv, int nt, int nn, Corner& c)
+{
+    std::string part[3];
+    int np = 0;
+    size_t i = 0;
+    for (;;) {
+        const size_t j = tok.find('/', i);
+        if (np < 3) part[np] = tok.substr(i, j == std::string::npos ? std::string::npos : j - i);
+        np++;
+        if (j == std::string::npos) break;
+        i = j + 1;
+    }
+    auto fix = [](const std::string& s, int n, bool& ok) {
+        if (s.empty()) return -1;
+        char* e = nullptr;
+        const long v = strtol(s.c_str(), &e, 10);
+        if (e == s.c_str() || *e) { ok = false; return -1; }
+        return (int)(v > 0 ? v - 1 : n + v);
+    };
+    bool ok = true;
+    c.v = fix(part[0], nv, ok);
+    c.vt = np > 1 ? fix(part[1], nt, ok) : -1;
+    c.vn = np > 2 ? fix(part[2], nn, ok) : -1;
+    return ok && !part[0].empty();
+}
+
+// polygon -> triangles, ear clipping in binary32 (see the header comment); appends corner triples
+void triangulate(const std::vector<Corner>& cs, const std::vector<F3>& pos, std::vector<Corner>& out)
+{
+    const int n = (int)cs.size();
+    if (n < 3) return;
+    if (n == 3) { out.insert(out.end(), cs.begin(), cs.end()); return; }
+    const float eps = 1.1920928955078125e-07f;
+    std::vector<bool> have(n);
+    std::vector<F3> P(n);
+    for (int k = 0; k < n; k++) {
+        have[k] = cs[k].v >= 0 && cs[k].v < (int)pos.size();
+        P[k] = have[k] ? pos[cs[k].v] : F3{0.f, 0.f, 0.f};
+    }
+    auto comp = [](const F3& p, int a) { return a == 0 ? p.x : (a == 1 ? p.y : p.z); };
+    int axes[2] = {1, 2};
+    for (int k = 0; k < n; k++) {
+        const int k1 = (k + 1) % n, k2 = (k + 2) % n;
+        if (!have[k] || !have[k1] || !have[k2]) continue;
+        const F3 &p0 = P[k], &p1 = P[k1], &p2 = P[k2];
+        const float e0x = p1.x - p0.x, e0y = p1.y - p0.y, e0z = p1.z - p0.z;
+        const float e1x = p2.x - p1.x, e1y = p2.y - p1.y, e1z = p2.z - p1.z;
+        const float cx = std::fabs(e0y * e1z - e0z * e1y), cy = std::fabs(e0z * e1x - e0x * e1z), cz = std::fabs(e0x * e1y - e0y * e1x);
+        if (cx > eps || cy > eps || cz > eps) {
+            if (!(cx > cy && cx > cz)) {
+                axes[0] = 0;
+                if (cz > cx && cz > cy) axes[1] = 1;
+            }
+            break;
+        }
+    }
+    float area = 0.f;
+    for (int k = 0; k < n; k++) {
+        const int k1 = (k + 1) % n;
+        if (!have[k] || !have[k1]) continue;
+        area = area + (comp(P[k], axes[0]) * comp(P[k1], axes[1]) - comp(P[k], axes[1]) * comp(P[k1], axes[0])) * 0.5f;
+    }
+    std::vector<int> rem(n);
+    for (int k = 0; k < n; k++) rem[k] = k;
+    int guess = 0, remaining_iter = n, prev_n = n;
+    while (rem.size() > 3 && remaining_iter > 0) {
+        const int m = (int)rem.size();
+        if (guess >= m) guess -= m;
+        if (prev_n != m) { prev_n = m; remaining_iter = m; }
+        else remaining_iter--;
+        int ind[3];
+        float vx[3], vy[3];
+        for (int k = 0; k < 3; k++) {
+            ind[k] = rem[(guess + k) % m];
+            vx[k] = have[ind[k]] ? comp(P[ind[k]], axes[0]) : 0.f;
+            vy[k] = have[ind[k]] ? comp(P[ind[k]], axes[1]) : 0.f;
+        }
+        const float cross = (vx[1] - vx[0]) * (vy[2] - vy[1]) - (vy[1] - vy[0]) * (vx[2] - vx[1]);
+        if (cross * area < 0.f) { guess++; continue; }
+        bool overlap = false;
+        for (int other = 3; other < m && !overlap; other++) {
+            const int qi = rem[(guess + other) % m];
+            if (!have[qi]) continue;
+            const float tx = comp(P[qi], axes[0]), ty = comp(P[qi], axes[1]);
+            bool c = false;
+            for (int i = 0, j = 2; i < 3; j = i++)                        // pnpoly on the candidate ear
+                if ((vy[i] > ty) != (vy[j] > ty) && tx < (vx[j] - vx[i]) * (ty - vy[i]) / (vy[j] - vy[i]) + vx[i]) c = !c;
+            overlap = c;
+        }
+        if (overlap) { guess++; continue; }
+        out.push_back(cs[ind[0]]); out.push_back(cs[ind[1]]); out.push_back(cs[ind[2]]);
+        rem.erase(rem.begin() + (guess + 1) % m);
+    }
+    if (rem.size() == 3) { out.push_back(cs[rem[0]]); out.push_back(cs[rem[1]]); out.push_back(cs[rem[2]]); }
+}
+
+// ---- images ------------------------------------------------------------------------------------
+bool read_file(const std::string& path, std::vector<uint8_t>& data)
+{
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    uint8_t buf[1 << 16];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof(buf), f)) > 0) data.insert(data.end(), buf, buf + n);
+    fclose(f);
+    return true;
+}
+uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+// undo the per-scanline filters of `rows` scanlines at raw[pos]; false on truncated data or a bad filter type
+bool png_unfilter(const std::vector<uint8_t>& raw, size_t& pos, int rows, size_t rowbytes, int bpp, std::vector<uint8_t>& out)
+{
+    out.assign((size_t)rows * rowbytes, 0);
+    std::vector<uint8_t> zero(rowbytes, 0);
+    for (int y = 0; y < rows; y++) {
+        if (pos + 1 + rowbytes > raw.size()) return false;
+        const int ft = raw[pos];
+        const uint8_t* ln = raw.data() + pos + 1;
+        pos += 1 + rowbytes;
+        uint8_t* cur = out.data() + (size_t)y * rowbytes;
+        const uint8_t* pv = y ? cur - rowbytes : zero.data();
+        if (ft > 4) return false;
+        for (size_t i = 0; i < rowbytes; i++) {
+            const int a = i >= (size_t)bpp ? cur[i - bpp] : 0, b = pv[i], c = i >= (size_t)bpp ? pv[i - bpp] : 0;
+            int pr = 0;
+            if (ft == 1) pr = a;
+            else if (ft == 2) pr = b;
+            else if (ft == 3) pr = (a + b) >> 1;
+            else if (ft == 4) {
+                const int pa = abs(b - c), pb = abs(a - c), pc = abs(a + b - 2 * c);
+                pr = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+            }
+            cur[i] = (uint8_t)(ln[i] + pr);
+        }
+    }
+    return true;
+}
+
+// PNG -> rgba8 as stbi_load(..., 4) gives it: 16-bit samples keep their high byte, gray of 1/2/4 bits is scaled to
+// 0..255, palette + tRNS alpha, a tRNS colour key gives alpha 0 (compared at the file's precision), Adam7
+bool decode_png(const std::vector<uint8_t>& d, Image& img)
+{
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    if (d.size() < 8 || memcmp(d.data(), sig, 8)) return false;
+    size_t pos = 8;
+    std::vector<uint8_t> idat, plte, trns;
+    bool has_hdr = false, has_trns = false, has_plte = false;
+    uint32_t w = 0, h = 0;
+    int depth = 0, ctype = 0, comp = 0, filt = 0, interlace = 0;
+    while (pos + 8 <= d.size()) {
+        const uint32_t n = be32(d.data() + pos);
+        const char* kind = (const char*)d.data() + pos + 4;
+        const size_t body = pos + 8, avail = body <= d.size() ? std::min<size_t>(n, d.size() - body) : 0;
+        if (!memcmp(kind, "IHDR", 4) && avail >= 13) {
+            w = be32(d.data() + body); h = be32(d.data() + body + 4);
+            depth = d[body + 8]; ctype = d[body + 9]; comp = d[body + 10]; filt = d[body + 11]; interlace = d[body + 12];
+            has_hdr = true;
+        } else if (!memcmp(kind, "PLTE", 4)) { plte.assign(d.begin() + body, d.begin() + body + avail); has_plte = true; }
+        else if (!memcmp(kind, "tRNS", 4)) { trns.assign(d.begin() + body, d.begin() + body + avail); has_trns = true; }
+        else if (!memcmp(kind, "IDAT", 4)) idat.insert(idat.end(), d.begin() + body, d.begin() + body + avail);
+        else if (!memcmp(kind, "IEND", 4)) break;
+        pos += 12 + (size_t)n;
+    }
+    if (!has_hdr || idat.empty()) return false;
+    if (w == 0 || h == 0 || w > (1u << 24) || h > (1u << 24) || comp || filt || interlace > 1) return false;
+    if (!(ctype == 0 || ctype == 2 || ctype == 3 || ctype == 4 || ctype == 6)) return false;
+    if (!(depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) return false;
+    if ((ctype == 3 && depth == 16) || ((ctype == 2 || ctype == 4 || ctype == 6) && depth < 8) || (ctype == 3 && !has_plte)) return false;
+    const int chans = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : 4;
+    const int bpp = std::max(1, chans * depth / 8);
+    // inflate
+    std::vector<uint8_t> raw;
+    {
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (inflateInit(&zs) != Z_OK) return false;
+        zs.next_in = idat.data(); zs.avail_in = (uInt)idat.size();
+        uint8_t buf[1 << 16];
+        int rc;
+        do {
+            zs.next_out = buf; zs.avail_out = sizeof(buf);
+            rc = inflate(&zs, Z_NO_FLUSH);
+            if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&zs); return false; }
+            raw.insert(raw.end(), buf, buf + (sizeof(buf) - zs.avail_out));
+        } while (rc != Z_STREAM_END);
+        inflateEnd(&zs);
+    }
+    std::vector<uint16_t> smp((size_t)w * h * chans, 0);
+    auto put = [&](const std::vector<uint8_t>& rows, int pw, int ph, size_t rowbytes, int x0, int y0, int dx, int dy) {
+        for (int y = 0; y < ph; y++) {
+            const uint8_t* r = rows.data() + (size_t)y * rowbytes;
+            for (int x = 0; x < pw; x++)
+                for (int c = 0; c < chans; c++) {
+                    uint16_t v;
+                    if (depth == 8) v = r[x * chans + c];
+                    else if (depth == 16) v = (uint16_t)((r[(x * chans + c) * 2] << 8) | r[(x * chans + c) * 2 + 1]);
+                    else { const int bit = x * depth; v = (uint16_t)((r[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1)); }
+                    smp[((size_t)(y0 + y * dy) * w + (x0 + x * dx)) * chans + c] = v;
+                }
+        }
+    };
+    size_t off = 0;
+    std::vector<uint8_t> rows;
+    if (!interlace) {
+        const size_t rb = ((size_t)w * chans * depth + 7) / 8;
+        if (!png_unfilter(raw, off, (int)h, rb, bpp, rows)) return false;
+        put(rows, (int)w, (int)h, rb, 0, 0, 1, 1);
+    } else {
+        static const int A7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};   // x0, y0, dx, dy
+        for (const auto& a : A7) {
+            const int pw = ((int)w - a[0] + a[2] - 1) / a[2], ph = ((int)h - a[1] + a[3] - 1) / a[3];
+            if (pw <= 0 || ph <= 0) continue;
+            const size_t rb = ((size_t)pw * chans * depth + 7) / 8;
+            if (!png_unfilter(raw, off, ph, rb, bpp, rows)) return false;
+            put(rows, pw, ph, rb, a[0], a[1], a[2], a[3]);
+        }
+    }
+    img.w = (int)w; img.h = (int)h;
+    img.px.assign((size_t)w * h, 0);
+    if (ctype == 3) {
+        uint8_t pal[256][4];
+        for (int k = 0; k < 256; k++) {                                     // an index past the palette reads black
+            const bool in = (size_t)k * 3 + 2 < plte.size();
+            pal[k][0] = in ? plte[k * 3] : 0; pal[k][1] = in ? plte[k * 3 + 1] : 0; pal[k][2] = in ? plte[k * 3 + 2] : 0;
+            pal[k][3] = (has_trns && (size_t)k < trns.size()) ? trns[k] : 255;
+        }
+        for (size_t p = 0; p < (size_t)w * h; p++) {
+            const uint8_t* c = pal[smp[p] & 255];
+            img.px[p] = c[0] | (c[1] << 8) | (c[2] << 16) | ((uint32_t)c[3] << 24);
+        }
+        return true;
+    }
+    bool keyed = false;
+    uint16_t key[3] = {0, 0, 0};
+    if (has_trns && (ctype == 0 || ctype == 2) && trns.size() / 2 >= (size_t)chans) {
+        keyed = true;
+        for (int c = 0; c < chans; c++) {
+            key[c] = (uint16_t)((trns[2 * c] << 8) | trns[2 * c + 1]);
+            if (depth <= 8) key[c] &= 255;                                   // stb keeps the low byte of an 8-bit key
+        }
+    }
+    const int scale = depth == 1 ? 255 : depth == 2 ? 85 : depth == 4 ? 17 : 1;
+    for (size_t p = 0; p < (size_t)w * h; p++) {
+        const uint16_t* s = &smp[p * chans];
+        uint8_t v[4];
+        for (int c = 0; c < chans; c++) v[c] = depth == 16 ? (uint8_t)(s[c] >> 8) : (uint8_t)(s[c] * scale);
+        uint8_t r, g, b, a;
+        if (ctype == 0 || ctype == 4) { r = g = b = v[0]; a = ctype == 4 ? v[1] : 255; }
+        else { r = v[0]; g = v[1]; b = v[2]; a = ctype == 6 ? v[3] : 255; }
+        if (keyed) {
+            bool eq = true;
+            for (int c = 0; c < chans; c++) eq = eq && s[c] == key[c];
+            a = eq ? 0 : 255;
+        }
+        img.px[p] = r | (g << 8) | (b << 16) | ((uint32_t)a << 24);
+    }
+    return true;
+}
+
+bool decode_ppm(const std::vector<uint8_t>& d, Image& img)       // binary 8-bit P6
+{
+    std::vector<std::string> toks;
+    size_t pos = 0;
+    while (toks.size() < 4) {
+        size_t end = pos;
+        while (end < d.size() && d[end] != '\n') end++;
+        if (end >= d.size()) return false;
+        for (const std::string& t : split_ws(std::string((const char*)d.data() + pos, end - pos))) toks.push_back(t);
+        pos = end + 1;
+    }
+    const long w = strtol(toks[1].c_str(), nullptr, 10), h = strtol(toks[2].c_str(), nullptr, 10), mx = strtol(toks[3].c_str(), nullptr, 10);
+    if (toks[0] != "P6" || mx != 255 || w <= 0 || h <= 0 || pos + (size_t)w * h * 3 > d.size()) return false;
+    img.w = (int)w; img.h = (int)h;
+    img.px.resize((size_t)w * h);
+    for (size_t p = 0; p < (size_t)w * h; p++) {
+        const uint8_t* c = d.data() + pos + p * 3;
+        img.px[p] = c[0] | (c[1] << 8) | (c[2] << 16) | 0xff000000u;
+    }
+    return true;
+}
+
+bool load_texture_file(const std::string& path, Image& img)
+{
+    std::vector<uint8_t> d;
+    if (!read_file(path, d)) return false;
+    bool ok = false;
+    if (d.size() >= 8 && d[0] == 0x89 && d[1] == 'P') ok = decode_png(d, img);
+    else if (d.size() >= 2 && d[0] == 'P' && d[1] == '6') ok = decode_ppm(d, img);
+    if (!ok) return false;
+    for (int y = 0; y < img.h / 2; y++)                                       // mirrored along y, Model.cpp:117-126
+        for (int x = 0; x < img.w; x++) std::swap(img.px[(size_t)y * img.w + x], img.px[(size_t)(img.h - 1 - y) * img.w + x]);
+    return true;
+}
+
+struct Mesh {
+    std::vector<F3> vertex, normal;
+    std::vector<F2> texcoord;
+    std::vector<uint32_t> index;        // 3 per triangle
+    fovpt_material material;
+    int diffuse_texture_id = -1;
+};
+
+fovpt_material reference_default_material()     // Material.h:48-69, the values every loadOBJ mesh keeps (Model.cpp:190-191)
+{
+    fovpt_material m;
+    memset(&m, 0, sizeof(m));
+    m.emission = {1.f, 1.f, 1.f}; m.color = {1.f, 0.f, 0.f}; m.absorption = {1.f, 1.f, 1.f};
+    m.eta = 1.4f; m.metallic = 0.5f; m.subsurface = 0.f; m.specular = 1.f; m.roughness = 1.f; m.specularTint = 1.f;
+    m.anisotropic = 0.f; m.sheen = 0.f; m.sheenTint = 0.f; m.clearcoat = 0.f; m.clearcoatGloss = 1.f; m.transmission = 0.4f;
+    m.bump = 0.f; m.bumpTile = {1.f, 1.f, 1.f}; m.flags = 0;
+    return m;
+}
+
+}  // namespace
+
+struct fovpt_model {
+    std::vector<Mesh> meshes;
+    std::vector<Image> textures;
+};
+
+extern "C" {
+
+int fovpt_model_load_obj(const char* obj_file, fovpt_model** out)
+{
+    if (!obj_file || !out) { fovpt_internal_set_error("fovpt_model_load_obj: null argument"); return FOVPT_E_INVALID; }
+    *out = nullptr;
+    const std::string path(obj_file);
+    const size_t slash = path.rfind('/');
+    const std::string dir = slash == std::string::npos ? std::string() : path.substr(0, slash + 1);       // :142-143
+    std::vector<std::string> lines;
+    if (!read_lines(path, lines)) { fovpt_internal_set_error(("Could not read OBJ model from " + path + " : cannot open file").c_str()); return FOVPT_E_INVALID; }
+
+    std::vector<F3> pos, nrm;
+    std::vector<F2> tex;
+    std::vector<MtlRec> materials;
+    std::map<std::string, int> mat_ids;
+    struct Shape { std::vector<Corner> faces; std::vector<int> mats; };       // 3 corners and one material id per triangle
+    std::vector<Shape> shapes;
+    Shape cur;
+    int cur_mat = -1;
+    auto flush = [&]() { if (!cur.mats.empty()) shapes.push_back(std::move(cur)); cur = Shape(); };
+    std::vector<Corner> cs, tris;
+    for (const std::string& line : lines) {
+        const std::vector<std::string> t = split_ws(line);
+        if (t.empty()) continue;
+        const std::string& k = t[0];
+        if (k == "v" && t.size() >= 4) pos.push_back({to_f(t[1]), to_f(t[2]), to_f(t[3])});
+        else if (k == "vn" && t.size() >= 4) nrm.push_back({to_f(t[1]), to_f(t[2]), to_f(t[3])});
+        else if (k == "vt" && t.size() >= 2) tex.push_back({to_f(t[1]), t.size() > 2 ? to_f(t[2]) : 0.f});
+        else if (k == "f") {
+            cs.clear(); tris.clear();
+            bool ok = true;
+            for (size_t a = 1; a < t.size(); a++) {
+                Corner c;
+                ok = ok && parse_corner(t[a], (int)pos.size(), (int)tex.size(), (int)nrm.size(), c);
+                cs.push_back(c);
+            }
+            if (!ok) { fovpt_internal_set_error(("Could not read OBJ model from " + path + " : bad face corner").c_str()); return FOVPT_E_INVALID; }
+            triangulate(cs, pos, tris);
+            for (size_t a = 0; a + 2 < tris.size(); a += 3) {
+                cur.faces.push_back(tris[a]); cur.faces.push_back(tris[a + 1]); cur.faces.push_back(tris[a + 2]);
+                cur.mats.push_back(cur_mat);
+            }
+        } else if (k == "o" || k == "g") flush();
+        else if (k == "usemtl") {
+            auto it = mat_ids.find(join_from(t, 1));
+            cur_mat = it == mat_ids.end() ? -1 : it->second;
+        } else if (k == "mtllib") {
+            for (size_t a = 1; a < t.size(); a++) {
+                std::vector<std::pair<std::string, MtlRec>> recs;
+                parse_mtl(dir + t[a], recs);
+                for (auto& r : recs)
+                    if (!mat_ids.count(r.first)) { mat_ids[r.first] = (int)materials.size(); materials.push_back(r.second); }
+            }
+        }
+    }
+    flush();
+    if (pos.empty()) { fovpt_internal_set_error(("Could not read OBJ model from " + path + " : no vertices").c_str()); return FOVPT_E_INVALID; }   // :160-162
+
+    std::unique_ptr<fovpt_model> model(new fovpt_model);
+    for (const Shape& shape : shapes) {
+        std::map<Corner, int> known;                       // per shape, :174
+        std::map<std::string, int> known_textures;         // per shape, :175
+        const std::set<int> ids(shape.mats.begin(), shape.mats.end());
+        for (int mid : ids) {
+            Mesh mesh;
+            mesh.material = reference_default_material();
+            auto add_vertex = [&](const Corner& c) -> int {                     // addVertex, :49-82
+                auto it = known.find(c);
+                if (it != known.end()) return it->second;
+                const int id = (int)mesh.vertex.size();
+                known[c] = id;
+                if (c.v < 0 || c.v >= (int)pos.size()) { mesh.vertex.push_back({0.f, 0.f, 0.f}); }      // (the reference reads out of bounds)
+                else mesh.vertex.push_back(pos[c.v]);
+                if (c.vn >= 0 && c.vn < (int)nrm.size()) while (mesh.normal.size() < mesh.vertex.size()) mesh.normal.push_back(nrm[c.vn]);
+                if (c.vt >= 0 && c.vt < (int)tex.size()) while (mesh.texcoord.size() < mesh.vertex.size()) mesh.texcoord.push_back(tex[c.vt]);
+                if (!mesh.texcoord.empty()) mesh.texcoord.resize(mesh.vertex.size(), F2{0.f, 0.f});
+                if (!mesh.normal.empty()) mesh.normal.resize(mesh.vertex.size(), F3{0.f, 0.f, 0.f});
+                return id;
+            };
+            for (size_t f = 0; f < shape.mats.size(); f++) {
+                if (shape.mats[f] != mid) continue;
+                for (int a = 0; a < 3; a++) mesh.index.push_back((uint32_t)add_vertex(shape.faces[3 * f + a]));
+            }
+            // (the reference sets material and texture inside the face loop, :190-201: the texture of a mesh that ends up
+            // empty -- every corner already known from an earlier material of the shape -- is still loaded and keeps its id)
+            mesh.diffuse_texture_id = -1;
+            if (mid >= 0) {
+                const MtlRec& m = materials[mid];
+                mesh.material.color = {m.kd[0], m.kd[1], m.kd[2]};
+                mesh.material.emission = {m.ke[0], m.ke[1], m.ke[2]};
+                if (!m.map_kd.empty()) {                                     // loadTexture, :84-136
+                    auto it = known_textures.find(m.map_kd);
+                    if (it == known_textures.end()) {
+                        std::string file = m.map_kd;
+                        for (char& ch : file) if (ch == '\\') ch = '/';
+                        Image img;
+                        int id = -1;
+                        if (load_texture_file(dir + file, img)) { id = (int)model->textures.size(); model->textures.push_back(std::move(img)); }
+                        it = known_textures.emplace(m.map_kd, id).first;
+                    }
+                    mesh.diffuse_texture_id = it->second;
+                }
+            }
+            if (mesh.vertex.empty()) continue;                              // :204-205
+            model->meshes.push_back(std::move(mesh));
+        }
+    }
+    *out = model.release();
+    return FOVPT_OK;
+}
+
+void fovpt_model_destroy(fovpt_model* m) { delete m; }
+
+int fovpt_model_counts(const fovpt_model* m, int* num_meshes, int* num_textures)
+{
+    if (!m) return FOVPT_E_INVALID;
+    if (num_meshes) *num_meshes = (int)m->meshes.size();
+    if (num_textures) *num_textures = (int)m->textures.size();
+    return FOVPT_OK;
+}
+
+int fovpt_model_get_mesh(const fovpt_model* m, int i, fovpt_model_mesh* out)
+{
+    if (!m || !out || i < 0 || i >= (int)m->meshes.size()) return FOVPT_E_INVALID;
+    const Mesh& s = m->meshes[i];
+    out->vertex = (const fovpt_float3*)s.vertex.data();
+    out->normal = s.normal.empty() ? nullptr : (const fovpt_float3*)s.normal.data();
+    out->texcoord = s.texcoord.empty() ? nullptr : (const float*)s.texcoord.data();
+    out->index = (const fovpt_uint3*)s.index.data();
+    out->num_vertices = (uint32_t)s.vertex.size(); out->num_normals = (uint32_t)s.normal.size();
+    out->num_texcoords = (uint32_t)s.texcoord.size(); out->num_triangles = (uint32_t)(s.index.size() / 3);
+    out->material = s.material;
+    out->diffuse_texture_id = s.diffuse_texture_id;
+    return FOVPT_OK;
+}
+
+int fovpt_model_get_texture(const fovpt_model* m, int i, const uint32_t** pixels, int* width, int* height)
+{
+    if (!m || i < 0 || i >= (int)m->textures.size()) return FOVPT_E_INVALID;
+    if (pixels) *pixels = m->textures[i].px.data();
+    if (width) *width = m->textures[i].w;
+    if (height) *height = m->textures[i].h;
+    return FOVPT_OK;
+}
+
+}  // extern "C"

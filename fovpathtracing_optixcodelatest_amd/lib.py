@@ -18,6 +18,7 @@ EXPORTS = [
     "fovpt_synchronize", "fovpt_download", "fovpt_get_stats", "fovpt_reset_stats", "fovpt_stream",
     "fovpt_probe_build_cdf", "fovpt_camera_uvw", "fovpt_debug_math", "fovpt_debug_buffer",
     "fovpt_gather_plan", "fovpt_gather_pack", "fovpt_gather_unpack",
+    "fovpt_model_load_obj", "fovpt_model_destroy", "fovpt_model_counts", "fovpt_model_get_mesh", "fovpt_model_get_texture",
 ]
 
 
@@ -102,8 +103,14 @@ def load():
     L.fovpt_gather_unpack.argtypes = [vp, vp, u32, vp]
     L.fovpt_debug_math.argtypes = [vp, i32, vp, vp, vp, sz]
     L.fovpt_debug_buffer.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(sz)]
+    L.fovpt_model_load_obj.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.fovpt_model_destroy.argtypes = [vp]
+    L.fovpt_model_destroy.restype = None
+    L.fovpt_model_counts.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.fovpt_model_get_mesh.argtypes = [vp, i32, C.POINTER(abi.ModelMesh)]
+    L.fovpt_model_get_texture.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32)]
     for name in EXPORTS:
-        if name not in ("fovpt_destroy", "fovpt_last_error", "fovpt_stream"):
+        if name not in ("fovpt_destroy", "fovpt_last_error", "fovpt_stream", "fovpt_model_destroy"):
             getattr(L, name).restype = i32
     _lib = L
     return L

@@ -507,8 +507,8 @@ def load_obj(obj_file: str) -> Model:
                 if fm != mid:
                     continue
                 idx.append(tuple(add_vertex(c) for c in face))
-            if not vtx:
-                continue
+            # (the reference sets material and texture inside the face loop, :190-201: the texture of a mesh that ends up
+            # empty -- every corner already known from an earlier material of the shape -- is still loaded and keeps its id)
             mat = Material.reference_default()
             tex_id = -1
             if mid >= 0:
@@ -518,17 +518,54 @@ def load_obj(obj_file: str) -> Model:
                 name = m["map_Kd"]
                 if name:
                     if name not in known_textures:
-                        px = _load_texture(os.path.join(model_dir, name.replace("\\\\", "/")))
+                        px = _load_texture(os.path.join(model_dir, name.replace("\\", "/")))       # :100-102
                         if px is None:
                             known_textures[name] = -1
                         else:
                             known_textures[name] = len(model.textures)
                             model.textures.append(px)
                     tex_id = known_textures[name]
+            if not vtx:
+                continue                                        # :204-205
             model.meshes.append(TriangleMesh(
                 np.asarray(vtx, np.float32).reshape(-1, 3), np.asarray(idx, np.uint32).reshape(-1, 3), mat,
                 np.asarray(tcs, np.float32).reshape(-1, 2) if tcs else None, tex_id))
     return model
+
+
+def load_obj_native(obj_file: str) -> Model:
+    """The same model through the library's host-side loader (fovpt_model_load_obj, csrc/model_loader.cpp) -- what a C++
+    caller gets from `loadOBJ` in include/Model.h.  Each mesh also carries `.normal` ((N,3) float32 or None)."""
+    import ctypes as C
+    from . import abi, lib
+    L = lib.load()
+    h = C.c_void_p()
+    lib.check(None, L.fovpt_model_load_obj(os.fsencode(obj_file), C.byref(h)))
+    try:
+        nm, nt = C.c_int(0), C.c_int(0)
+        lib.check(None, L.fovpt_model_counts(h, C.byref(nm), C.byref(nt)))
+        model = Model()
+
+        def arr(ptr, n, cols, dtype):
+            if not ptr or n == 0:
+                return None
+            return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), (n * cols,)).view(dtype).reshape(n, cols).copy()
+        for k in range(nm.value):
+            d = abi.ModelMesh()
+            lib.check(None, L.fovpt_model_get_mesh(h, k, C.byref(d)))
+            mat = Material()
+            C.memmove(C.byref(mat), C.byref(d.material), C.sizeof(Material))
+            mesh = TriangleMesh(arr(d.vertex, d.num_vertices, 3, np.float32), arr(d.index, d.num_triangles, 3, np.uint32), mat,
+                                arr(d.texcoord, d.num_texcoords, 2, np.float32), int(d.diffuse_texture_id))
+            mesh.normal = arr(d.normal, d.num_normals, 3, np.float32)
+            model.meshes.append(mesh)
+        for k in range(nt.value):
+            px, w, hh = C.c_void_p(), C.c_int(0), C.c_int(0)
+            lib.check(None, L.fovpt_model_get_texture(h, k, C.byref(px), C.byref(w), C.byref(hh)))
+            model.textures.append(np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_uint32)), (hh.value, w.value)).copy())
+        return model
+    finally:
+        L.fovpt_model_destroy(h)
 
 
 # ------------------------------------------------------------------------------------------

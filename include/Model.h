@@ -1,6 +1,9 @@
 // Model.h -- drop-in for PT_sv5_/Model.h:10-43 (scene layout consumed by the SampleRenderer ctor).
 #pragma once
 #include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
 #include <vector>
 #include "Material.h"
 
@@ -52,4 +55,43 @@ inline void addBox(Model* model, Material& mat, const float3& pos, const float3&
     mesh->material = mat;
     mesh->diffuseTextureID = -1;     // the reference leaves the default 1 here and reads textureObjects[1]
     model->meshes.push_back(mesh);
+}
+
+// loadOBJ of Model.cpp:138-217 (declared Model.h:42): the scene as the reference's loader builds it -- one mesh per
+// (shape, material), per-shape vertex and texture maps, Kd -> color, Ke -> emission, textures as stbi_load gives them,
+// mirrored along y.  The work is done by the library's host-side loader (fovpt_model_load_obj, csrc/model_loader.cpp);
+// throws std::runtime_error like the reference (:160-162).  Link against libfovpt.so.
+inline Model* loadOBJ(const std::string& objFile)
+{
+    fovpt_model* h = nullptr;
+    if (fovpt_model_load_obj(objFile.c_str(), &h) != FOVPT_OK) throw std::runtime_error(fovpt_last_error(nullptr));
+    int nm = 0, nt = 0;
+    fovpt_model_counts(h, &nm, &nt);
+    Model* model = new Model;
+    for (int k = 0; k < nm; k++) {
+        fovpt_model_mesh d;
+        fovpt_model_get_mesh(h, k, &d);
+        TriangleMesh* mesh = new TriangleMesh;
+        mesh->vertex.resize(d.num_vertices); mesh->normal.resize(d.num_normals); mesh->texcoord.resize(d.num_texcoords); mesh->index.resize(d.num_triangles);
+        if (d.num_vertices) std::memcpy(mesh->vertex.data(), d.vertex, sizeof(float3) * d.num_vertices);
+        if (d.num_normals) std::memcpy(mesh->normal.data(), d.normal, sizeof(float3) * d.num_normals);
+        for (uint32_t i = 0; i < d.num_texcoords; i++) mesh->texcoord[i] = make_float2(d.texcoord[2 * i], d.texcoord[2 * i + 1]);
+        if (d.num_triangles) std::memcpy(mesh->index.data(), d.index, sizeof(uint3) * d.num_triangles);
+        static_assert(sizeof(float3) == sizeof(fovpt_float3) && sizeof(uint3) == sizeof(fovpt_uint3), "vector layouts");
+        std::memcpy(&mesh->material, &d.material, sizeof(Material));
+        mesh->diffuseTextureID = d.diffuse_texture_id;
+        model->meshes.push_back(mesh);
+    }
+    for (int k = 0; k < nt; k++) {
+        const uint32_t* px = nullptr;
+        int w = 0, hh = 0;
+        fovpt_model_get_texture(h, k, &px, &w, &hh);
+        Texture* t = new Texture;
+        t->resolution = make_int2(w, hh);
+        t->pixel = new uint32_t[(size_t)w * hh];
+        std::memcpy(t->pixel, px, sizeof(uint32_t) * (size_t)w * hh);
+        model->textures.push_back(t);
+    }
+    fovpt_model_destroy(h);
+    return model;
 }

@@ -306,7 +306,29 @@ int fovpt_camera_uvw(const fovpt_float3* eye, const fovpt_float3* lookat, const 
 #define FOVPT_OP_SQRT   7
 #define FOVPT_OP_DIV    8
 #define FOVPT_OP_RSQRTD 9   /* (float)(1.0 / (double)sqrtf(a)), maths.h:98 */
-#define FOVPT_OP_UNORM8 10  /* texel channel (uint8)a / 255.0f as the shading kernel computes it */
+#define FOVPT_OP_UNORM8 10  /* ---- Scene ingestion on the host: what loadOBJ returns, PT_sv5_/Model.cpp:138-217 --------------------
+ * (with addVertex :49-82 and loadTexture :84-136, i.e. the vendored tinyobjloader with triangulate = true and
+ * stbi_load(..., STBI_rgb_alpha) mirrored along y).  Plain host code, no GPU needed.  One mesh per (shape, material id);
+ * PNG and binary PPM textures are decoded, any other format counts as "could not load" (texture id -1, as :129-131).
+ * The arrays stay owned by the model; include/Model.h wraps this as `Model* loadOBJ(const std::string&)`.
+ * Errors: FOVPT_E_INVALID, text from fovpt_last_error(NULL) ("Could not read OBJ model from ...", :160-162).          */
+typedef struct fovpt_model fovpt_model;
+typedef struct fovpt_model_mesh {
+    const fovpt_float3* vertex;      /* TriangleMesh::vertex                                   */
+    const fovpt_float3* normal;      /* TriangleMesh::normal, NULL when the mesh has none      */
+    const float* texcoord;           /* TriangleMesh::texcoord as (u, v) pairs, NULL when none */
+    const fovpt_uint3* index;        /* TriangleMesh::index                                    */
+    uint32_t num_vertices, num_normals, num_texcoords, num_triangles;
+    fovpt_material material;         /* reference defaults + Kd -> color, Ke -> emission (:190-191) */
+    int32_t diffuse_texture_id;      /* index into the model's textures, or -1                 */
+} fovpt_model_mesh;
+int fovpt_model_load_obj(const char* obj_file, fovpt_model** out);
+void fovpt_model_destroy(fovpt_model* model);
+int fovpt_model_counts(const fovpt_model* model, int* num_meshes, int* num_textures);
+int fovpt_model_get_mesh(const fovpt_model* model, int i, fovpt_model_mesh* out);
+int fovpt_model_get_texture(const fovpt_model* model, int i, const uint32_t** pixels, int* width, int* height);
+
+/* texel channel (uint8)a / 255.0f as the shading kernel computes it */
 int fovpt_debug_math(fovpt_ctx* ctx, int op, const float* a, const float* b, float* out, size_t n);
 /* tests/diagnostics only: device address and size of an internal buffer ("sq_occ", "counters", "hit", "bvh_nodes", ...) */
 int fovpt_debug_buffer(fovpt_ctx* ctx, const char* name, void** ptr, size_t* bytes);

@@ -1,5 +1,6 @@
 // Uses the drop-in C++ API the way PT_sv5_/main.cpp:297-306,423 does, on a box scene built with
-// addBox, and writes the rgba8 frame + accum to files for the python test to compare with the oracle.
+// addBox (or, with a second argument, on the OBJ file it names, through loadOBJ), and writes the rgba8 frame to a file
+// for the python test to compare with the oracle.
 #include <cstdio>
 #include <vector>
 #include "SimplePathtracer.h"
@@ -14,11 +15,16 @@ int main(int argc, char** argv)
 {
     const char* out = argc > 1 ? argv[1] : "shim_out.bin";
     try {
-        Model* model = new Model;
-        Material grey; grey.color = make_float3(0.7f, 0.7f, 0.7f); grey.emission = make_float3(0.0f);
-        Material red; red.color = make_float3(0.8f, 0.1f, 0.1f); red.emission = make_float3(0.0f);
-        addBox(model, grey, make_float3(0, -1.0f, 0), make_float3(6, 0.5f, 6));
-        addBox(model, red, make_float3(0, 0.5f, 0), make_float3(1, 1, 1));
+        Model* model;
+        if (argc > 2) {
+            model = loadOBJ(argv[2]);                 // main.cpp:130-145: the scene from an OBJ file
+        } else {
+            model = new Model;
+            Material grey; grey.color = make_float3(0.7f, 0.7f, 0.7f); grey.emission = make_float3(0.0f);
+            Material red; red.color = make_float3(0.8f, 0.1f, 0.1f); red.emission = make_float3(0.0f);
+            addBox(model, grey, make_float3(0, -1.0f, 0), make_float3(6, 0.5f, 6));
+            addBox(model, red, make_float3(0, 0.5f, 0), make_float3(1, 1, 1));
+        }
         const int2 fbSize = make_int2(160, 96);
         std::vector<float4> sky((size_t)fbSize.x * fbSize.y, make_float4(2.5f, 2.5f, 2.5f, 1.0f));   // loadColor, main.cpp:175-187
         ProbeData probe;

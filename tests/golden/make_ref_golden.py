@@ -24,7 +24,8 @@ import ref_cases  # noqa: E402
 from common import encode_hdr_rle, encode_png  # noqa: E402
 
 OBJ = """# three shapes, three materials, quads, negative indices, all corner syntaxes, a texture used by two shapes,
-# a corner shared by two materials of one shape
+# a corner shared by two materials of one shape, a (shape, material) whose corners are all known already (its mesh is
+# dropped, its texture is loaded all the same and takes an id)
 mtllib scene.mtl
 v 0 0 0
 v 1 0 0
@@ -64,6 +65,11 @@ usemtl lamp
 f 5 6 7
 f 6 7 8
 f 3 4 5
+usemtl tiles
+f 1 2 3
+g after
+usemtl tiles
+f 1/1 2/2 6/3
 """
 MTL = """newmtl red
 Kd 0.8 0.1 0.2

@@ -202,6 +202,28 @@ def test_cpp_dropin_shim_end_to_end(oracle, tmp_path):
     S, F = make_oracle(oracle, model, scenes.ambient_probe(160, 96, 2.5), cam, (160, 96))
     oracle.render(S, F, cfg_foveated(12, 36, (1, 2, 8)))
     assert np.array_equal(px, F.frame)
+    # the same program on an OBJ file: loadOBJ of include/Model.h (the library's host-side loader) -> SampleRenderer
+    _write_textured_obj(tmp_path)
+    res = subprocess.run([exe, out, str(tmp_path / "s.obj")], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    px = np.fromfile(out, np.uint32).reshape(96, 160)
+    from fovpathtracing_optixcodelatest_amd import loaders
+    S, F = make_oracle(oracle, loaders.load_obj(str(tmp_path / "s.obj")), scenes.ambient_probe(160, 96, 2.5), cam, (160, 96))
+    oracle.render(S, F, cfg_foveated(12, 36, (1, 2, 8)))
+    assert np.array_equal(px, F.frame)
+
+
+def _write_textured_obj(tmp_path):
+    rng = np.random.default_rng(4)
+    tex = rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)
+    with open(tmp_path / "t.ppm", "wb") as f:
+        f.write(b"P6\n8 8\n255\n" + tex.tobytes())
+    (tmp_path / "s.mtl").write_text("newmtl floor\nKd 0.5 0.5 0.5\nmap_Kd t.ppm\nnewmtl box\nKd 0.9 0.3 0.1\nKe 2 2 2\n")
+    obj = ["mtllib s.mtl", "v -5 0 -5", "v 5 0 -5", "v 5 0 5", "v -5 0 5", "vt 0 0", "vt 3 0", "vt 3 3", "vt 0 3",
+           "usemtl floor", "f 1/1 4/4 3/3 2/2",
+           "o box", "v -1 0 -1", "v 1 0 -1", "v 1 2 -1", "v -1 2 -1", "v -1 0 1", "v 1 0 1", "v 1 2 1", "v -1 2 1",
+           "usemtl box", "f 5 8 7 6", "f 9 10 11 12", "f 5 9 12 8", "f 6 7 11 10", "f 8 12 11 7"]
+    (tmp_path / "s.obj").write_text("\n".join(obj) + "\n")
 
 
 def test_error_behaviour():
@@ -351,16 +373,7 @@ def test_obj_loaded_textured_scene(oracle, tmp_path):
     """OBJ + MTL + map_Kd through loaders.load_obj (loadOBJ semantics), rendered and checked: exercises the
     textured-albedo path (barycentric texcoords + bilinear fetch, deviceProgram.cu:655-670) on real loader output."""
     from fovpathtracing_optixcodelatest_amd import loaders
-    rng = np.random.default_rng(4)
-    tex = rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)
-    with open(tmp_path / "t.ppm", "wb") as f:
-        f.write(b"P6\n8 8\n255\n" + tex.tobytes())
-    (tmp_path / "s.mtl").write_text("newmtl floor\nKd 0.5 0.5 0.5\nmap_Kd t.ppm\nnewmtl box\nKd 0.9 0.3 0.1\nKe 2 2 2\n")
-    obj = ["mtllib s.mtl", "v -5 0 -5", "v 5 0 -5", "v 5 0 5", "v -5 0 5", "vt 0 0", "vt 3 0", "vt 3 3", "vt 0 3",
-           "usemtl floor", "f 1/1 4/4 3/3 2/2",
-           "o box", "v -1 0 -1", "v 1 0 -1", "v 1 2 -1", "v -1 2 -1", "v -1 0 1", "v 1 0 1", "v 1 2 1", "v -1 2 1",
-           "usemtl box", "f 5 8 7 6", "f 9 10 11 12", "f 5 9 12 8", "f 6 7 11 10", "f 8 12 11 7"]
-    (tmp_path / "s.obj").write_text("\n".join(obj) + "\n")
+    _write_textured_obj(tmp_path)
     model = loaders.load_obj(str(tmp_path / "s.obj"))
     assert model.num_triangles == 12 and len(model.textures) == 1
     cam = dict(eye=(4.0, 3.0, 6.0), lookat=(0.0, 0.8, 0.0), up=(0.0, 1.0, 0.0), fovy=45.0)
