@@ -285,8 +285,10 @@ bool decode_png(const std::vector<uint8_t>& d, Image& img)
     if (!(ctype == 0 || ctype == 2 || ctype == 3 || ctype == 4 || ctype == 6)) return false;
     if (!(depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) return false;
     if ((ctype == 3 && depth == 16) || ((ctype == 2 || ctype == 4 || ctype == 6) && depth < 8) || (ctype == 3 && !has_plte)) return false;
+    if ((uint64_t)w * h > (1ull << 28)) return false;                     // (stb's own limit is 2^24 per side; this bounds the allocation)
     const int chans = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : 4;
     const int bpp = std::max(1, chans * depth / 8);
+    const size_t raw_max = ((size_t)w * chans * depth / 8 + 16) * ((size_t)h + 16) + 1024;   // all scanlines + filter bytes, 7 passes' padding
     // inflate
     std::vector<uint8_t> raw;
     {
@@ -301,6 +303,8 @@ bool decode_png(const std::vector<uint8_t>& d, Image& img)
             rc = inflate(&zs, Z_NO_FLUSH);
             if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&zs); return false; }
             raw.insert(raw.end(), buf, buf + (sizeof(buf) - zs.avail_out));
+            if (raw.size() > raw_max) { inflateEnd(&zs); return false; }     // more data than the header's image can hold
+            if (rc == Z_OK && zs.avail_in == 0 && zs.avail_out != 0) { inflateEnd(&zs); return false; }   // truncated stream
         } while (rc != Z_STREAM_END);
         inflateEnd(&zs);
     }
