@@ -415,6 +415,83 @@ bool load_texture_file(const std::string& path, Image& img)
     return true;
 }
 
+// ---- float4 texels as stbi_loadf(file, &w, &h, &n, 4) gives them (loadProbe, PT_sv5_/main.cpp:160-171) -------------
+// Radiance .hdr: "#?RADIANCE" / "#?RGBE", header lines up to the first empty one with FORMAT=32-bit_rle_rgbe among them,
+// "-Y h +X w"; new-style RLE scanlines when 8 <= w < 32768 and the first scanline starts with the marker, flat RGBE
+// quadruples otherwise; texel = (r, g, b) * 2^(e - 136), alpha 1, e == 0 -> (0, 0, 0, 1).  8-bit images (PNG, PPM here) go
+// through stb's ldr-to-hdr conversion: colour (float)pow(c / 255.0f, 2.2f), alpha c / 255.0f.
+bool decode_hdr(const std::vector<uint8_t>& d, int& w, int& h, std::vector<float>& out, std::string& why)
+{
+    size_t pos = 0;
+    auto token = [&]() {
+        size_t end = pos;
+        while (end < d.size() && d[end] != '\n') end++;
+        std::string line((const char*)d.data() + pos, end - pos);
+        pos = std::min(d.size(), end + 1);
+        return line;
+    };
+    const std::string first = token();
+    if (first != "#?RADIANCE" && first != "#?RGBE") { why = "not a Radiance HDR file"; return false; }
+    bool valid = false;
+    for (;;) {
+        const std::string line = token();
+        if (line.empty()) break;
+        if (line == "FORMAT=32-bit_rle_rgbe") valid = true;
+        if (pos >= d.size()) break;
+    }
+    if (!valid) { why = "unsupported HDR format (FORMAT=32-bit_rle_rgbe expected)"; return false; }
+    const std::vector<std::string> parts = split_ws(token());
+    if (parts.size() != 4 || parts[0] != "-Y" || parts[2] != "+X") { why = "unsupported HDR data layout (-Y h +X w expected)"; return false; }
+    const long hh = strtol(parts[1].c_str(), nullptr, 10), ww = strtol(parts[3].c_str(), nullptr, 10);
+    if (ww <= 0 || hh <= 0 || (uint64_t)ww * (uint64_t)hh > (1ull << 28)) { why = "bad HDR size"; return false; }
+    w = (int)ww; h = (int)hh;
+    const uint8_t* data = d.data() + pos;
+    const size_t size = d.size() - pos, npx = (size_t)w * h;
+    std::vector<uint8_t> rows;
+    const uint8_t* rgbe = nullptr;
+    const bool rle = !(w < 8 || w >= 32768) && !(size >= 4 && !(data[0] == 2 && data[1] == 2 && !(data[2] & 0x80)));
+    if (!rle) {
+        if (size < npx * 4) { why = "truncated HDR data"; return false; }
+        rgbe = data;
+    } else {
+        rows.assign(npx * 4, 0);
+        size_t p = 0;
+        for (int j = 0; j < h; j++) {
+            if (p + 4 > size) { why = "truncated HDR data"; return false; }
+            if (data[p] != 2 || data[p + 1] != 2 || (data[p + 2] & 0x80)) { why = "a scanline is not run-length encoded"; return false; }
+            if (((data[p + 2] << 8) | data[p + 3]) != w) { why = "invalid decoded scanline length"; return false; }
+            p += 4;
+            for (int k = 0; k < 4; k++) {
+                int i = 0;
+                while (i < w) {
+                    if (p >= size) { why = "truncated HDR data"; return false; }
+                    int count = data[p++];
+                    if (count > 128) {
+                        count -= 128;
+                        if (count > w - i || p >= size) { why = "bad RLE data in HDR"; return false; }
+                        const uint8_t v = data[p++];
+                        for (int c = 0; c < count; c++) rows[((size_t)j * w + i + c) * 4 + k] = v;
+                    } else {
+                        if (count == 0 || count > w - i || p + count > size) { why = "bad RLE data in HDR"; return false; }
+                        for (int c = 0; c < count; c++) rows[((size_t)j * w + i + c) * 4 + k] = data[p + c];
+                        p += count;
+                    }
+                    i += count;
+                }
+            }
+        }
+        rgbe = rows.data();
+    }
+    out.resize(npx * 4);
+    for (size_t q = 0; q < npx; q++) {
+        const int e = rgbe[q * 4 + 3];
+        const float f1 = e ? std::ldexp(1.0f, e - 136) : 0.0f;
+        out[q * 4 + 0] = (float)rgbe[q * 4 + 0] * f1; out[q * 4 + 1] = (float)rgbe[q * 4 + 1] * f1; out[q * 4 + 2] = (float)rgbe[q * 4 + 2] * f1;
+        out[q * 4 + 3] = 1.0f;
+    }
+    return true;
+}
+
 struct Mesh {
     std::vector<F3> vertex, normal;
     std::vector<F2> texcoord;
@@ -586,5 +663,39 @@ int fovpt_model_get_texture(const fovpt_model* m, int i, const uint32_t** pixels
     if (height) *height = m->textures[i].h;
     return FOVPT_OK;
 }
+
+int fovpt_image_load_float4(const char* file, int* width, int* height, fovpt_float4** texels)
+{
+    if (!file || !width || !height || !texels) { fovpt_internal_set_error("fovpt_image_load_float4: null argument"); return FOVPT_E_INVALID; }
+    *texels = nullptr;
+    std::vector<uint8_t> d;
+    if (!read_file(file, d)) { fovpt_internal_set_error((std::string("Could not read image ") + file).c_str()); return FOVPT_E_INVALID; }
+    std::vector<float> px;
+    int w = 0, h = 0;
+    if (d.size() >= 6 && (!memcmp(d.data(), "#?RADIANCE", std::min<size_t>(10, d.size())) || !memcmp(d.data(), "#?RGBE", 6))) {
+        std::string why;
+        if (!decode_hdr(d, w, h, px, why)) { fovpt_internal_set_error((std::string(file) + ": " + why).c_str()); return FOVPT_E_INVALID; }
+    } else {
+        Image img;
+        bool ok = false;
+        if (d.size() >= 8 && d[0] == 0x89 && d[1] == 'P') ok = decode_png(d, img);
+        else if (d.size() >= 2 && d[0] == 'P' && d[1] == '6') ok = decode_ppm(d, img);
+        if (!ok) { fovpt_internal_set_error((std::string(file) + ": not an image this loader reads (.hdr, .png, binary .ppm)").c_str()); return FOVPT_E_INVALID; }
+        w = img.w; h = img.h;
+        px.resize((size_t)w * h * 4);
+        for (size_t q = 0; q < (size_t)w * h; q++) {                         // stbi__ldr_to_hdr: gamma 2.2, scale 1
+            const uint32_t c = img.px[q];
+            for (int k = 0; k < 3; k++) px[q * 4 + k] = (float)(std::pow((double)((float)((c >> (8 * k)) & 255u) / 255.0f), (double)2.2f) * 1.0f);
+            px[q * 4 + 3] = (float)(c >> 24) / 255.0f;
+        }
+    }
+    fovpt_float4* out = (fovpt_float4*)malloc(sizeof(fovpt_float4) * (size_t)w * h);
+    if (!out) { fovpt_internal_set_error("fovpt_image_load_float4: out of memory"); return FOVPT_E_NOMEM; }
+    memcpy(out, px.data(), sizeof(float) * px.size());
+    *width = w; *height = h; *texels = out;
+    return FOVPT_OK;
+}
+
+void fovpt_image_free(fovpt_float4* texels) { free(texels); }
 
 }  // extern "C"

@@ -19,6 +19,7 @@ EXPORTS = [
     "fovpt_probe_build_cdf", "fovpt_camera_uvw", "fovpt_debug_math", "fovpt_debug_buffer",
     "fovpt_gather_plan", "fovpt_gather_pack", "fovpt_gather_unpack",
     "fovpt_model_load_obj", "fovpt_model_destroy", "fovpt_model_counts", "fovpt_model_get_mesh", "fovpt_model_get_texture",
+    "fovpt_image_load_float4", "fovpt_image_free",
 ]
 
 
@@ -109,8 +110,11 @@ def load():
     L.fovpt_model_counts.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.fovpt_model_get_mesh.argtypes = [vp, i32, C.POINTER(abi.ModelMesh)]
     L.fovpt_model_get_texture.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32)]
+    L.fovpt_image_load_float4.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(vp)]
+    L.fovpt_image_free.argtypes = [vp]
+    L.fovpt_image_free.restype = None
     for name in EXPORTS:
-        if name not in ("fovpt_destroy", "fovpt_last_error", "fovpt_stream", "fovpt_model_destroy"):
+        if name not in ("fovpt_destroy", "fovpt_last_error", "fovpt_stream", "fovpt_model_destroy", "fovpt_image_free"):
             getattr(L, name).restype = i32
     _lib = L
     return L

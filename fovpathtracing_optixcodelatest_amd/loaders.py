@@ -671,12 +671,15 @@ def load_hdr(path: str) -> np.ndarray:
 
 
 def ldr_to_float4(rgba8: np.ndarray) -> np.ndarray:
-    """What stbi_loadf(file, ..., 4) makes of an 8-bit image (stb_image's stbi__ldr_to_hdr with its default gamma 2.2 and
-    scale 1): colour channels powf(c / 255, 2.2), alpha c / 255.  (libm's powf, so equal to stb's floats up to the last
-    bit of a vectorised powf.)"""
+    """What stbi_loadf(file, ..., 4) makes of an 8-bit image (stb_image's stbi__ldr_to_hdr with its default gamma 2.2f and
+    scale 1): colour channels (float)pow(c / 255.0f, 2.2f) -- the binary32 quotient raised in binary64 by libm's pow --
+    alpha c / 255.0f."""
+    import math
     c = rgba8.astype(np.float32) / np.float32(255.0)
+    g = float(np.float32(2.2))
+    lut = np.array([math.pow(float(np.float32(k) / np.float32(255.0)), g) for k in range(256)], np.float64).astype(np.float32)   # libm pow, as stb
     out = np.empty(rgba8.shape[:2] + (4,), np.float32)
-    out[..., :3] = np.power(c[..., :3], np.float32(2.2), dtype=np.float32)
+    out[..., :3] = lut[rgba8[..., :3]]
     out[..., 3] = c[..., 3]
     return out
 
@@ -700,6 +703,19 @@ def load_probe_texels(path: str) -> np.ndarray:
     else:
         raise ValueError("%s: not an image stbi_loadf can read here (.hdr, .png, .ppm, .tga)" % path)
     return ldr_to_float4(rgba)
+
+
+def load_probe_texels_native(path: str) -> np.ndarray:
+    """The same texels through the library (fovpt_image_load_float4, csrc/model_loader.cpp): .hdr, .png, binary .ppm."""
+    import ctypes as C
+    from . import lib
+    L = lib.load()
+    w, h, px = C.c_int(0), C.c_int(0), C.c_void_p()
+    lib.check(None, L.fovpt_image_load_float4(os.fsencode(path), C.byref(w), C.byref(h), C.byref(px)))
+    try:
+        return np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_float)), (h.value, w.value, 4)).copy()
+    finally:
+        L.fovpt_image_free(px)
 
 
 def load_probe(hdr_file: str):

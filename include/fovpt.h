@@ -328,6 +328,14 @@ int fovpt_model_counts(const fovpt_model* model, int* num_meshes, int* num_textu
 int fovpt_model_get_mesh(const fovpt_model* model, int i, fovpt_model_mesh* out);
 int fovpt_model_get_texture(const fovpt_model* model, int i, const uint32_t** pixels, int* width, int* height);
 
+/* The float4 texels loadProbe hands to ProbeData::BuildCDF (PT_sv5_/main.cpp:160-171): what
+ * stbi_loadf(file, &w, &h, &n, 4) returns -- Radiance .hdr as it is (RLE and flat scanlines, alpha 1), 8-bit PNG / PPM
+ * through stb's gamma-2.2 conversion.  *texels is malloc'ed, width * height entries, row 0 first; release it with
+ * fovpt_image_free.  Errors: FOVPT_E_INVALID with fovpt_last_error(NULL) (the reference does not check stbi_loadf's
+ * result and would build the CDF over a null pointer).                                                               */
+int fovpt_image_load_float4(const char* file, int* width, int* height, fovpt_float4** texels);
+void fovpt_image_free(fovpt_float4* texels);
+
 /* texel channel (uint8)a / 255.0f as the shading kernel computes it */
 int fovpt_debug_math(fovpt_ctx* ctx, int op, const float* a, const float* b, float* out, size_t n);
 /* tests/diagnostics only: device address and size of an internal buffer ("sq_occ", "counters", "hit", "bvh_nodes", ...) */
