@@ -28,7 +28,14 @@ int main(int argc, char** argv)
         const int2 fbSize = make_int2(160, 96);
         std::vector<float4> sky((size_t)fbSize.x * fbSize.y, make_float4(2.5f, 2.5f, 2.5f, 1.0f));   // loadColor, main.cpp:175-187
         ProbeData probe;
-        probe.width = fbSize.x; probe.height = fbSize.y; probe.data = sky.data();
+        if (argc > 3) {                               // loadProbe, main.cpp:160-171, without stb_image
+            float4* data = nullptr;
+            int resX = 0, resY = 0;
+            if (fovpt_image_load_float4(argv[3], &resX, &resY, (fovpt_float4**)&data)) throw std::runtime_error(fovpt_last_error(nullptr));
+            probe.width = resX; probe.height = resY; probe.data = data;
+        } else {
+            probe.width = fbSize.x; probe.height = fbSize.y; probe.data = sky.data();
+        }
         probe.BuildCDF();
         sutil::Camera camera(make_float3(4, 3, 6), make_float3(0, 0.5f, 0), make_float3(0, 1, 0), 45.0f, fbSize.x / float(fbSize.y));
 

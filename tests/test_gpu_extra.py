@@ -211,6 +211,18 @@ def test_cpp_dropin_shim_end_to_end(oracle, tmp_path):
     S, F = make_oracle(oracle, loaders.load_obj(str(tmp_path / "s.obj")), scenes.ambient_probe(160, 96, 2.5), cam, (160, 96))
     oracle.render(S, F, cfg_foveated(12, 36, (1, 2, 8)))
     assert np.array_equal(px, F.frame)
+    # ... and with the probe from a Radiance file: loadProbe's stbi_loadf replaced by fovpt_image_load_float4 (main.cpp:160-171)
+    from common import encode_hdr_rle
+    rng = np.random.default_rng(17)
+    rgbe = rng.integers(1, 256, (16, 32, 4), dtype=np.uint8)
+    rgbe[..., 3] = rng.integers(126, 131, (16, 32))
+    (tmp_path / "sky.hdr").write_bytes(encode_hdr_rle(rgbe))
+    res = subprocess.run([exe, out, str(tmp_path / "s.obj"), str(tmp_path / "sky.hdr")], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    px = np.fromfile(out, np.uint32).reshape(96, 160)
+    S, F = make_oracle(oracle, loaders.load_obj(str(tmp_path / "s.obj")), loaders.load_probe_texels(str(tmp_path / "sky.hdr")), cam, (160, 96))
+    oracle.render(S, F, cfg_foveated(12, 36, (1, 2, 8)))
+    assert np.array_equal(px, F.frame)
 
 
 def _write_textured_obj(tmp_path):
