@@ -191,6 +191,9 @@ def main():
     if args.child_frames:
         return child_main(args.child_frames)
 
+    # the host driver of this pool only supports dmabuf IPC: without this RCCL's buffer exchange between the ranks fails with
+    # hipIpcGetMemHandle: invalid argument (already exported on the GPU boxes; kept for any other launcher)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
