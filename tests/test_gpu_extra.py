@@ -322,6 +322,53 @@ def test_bistro_class_scene_full_size_against_oracle(oracle, scene):
     assert (st.radiance_rays, st.shadow_rays) == (cnt.lib_radiance, cnt.lib_shadow)
 
 
+@pytest.mark.parametrize("name,size,radii,depth,world", [("C4", (2560, 1440), (197, 643), 4, 4), ("C5 (one eye)", (2160, 2160), (296, 964), 8, 8)])
+def test_tile_split_of_the_multi_gpu_configurations_at_full_size(name, size, radii, depth, world):
+    """BASELINE.json configs[3] and [4] as they are configured -- 4 / 8 GPUs, tile split, gather of the final framebuffer --
+    with the ranks run one after the other on this one GPU: every rank renders only the launch indices it owns and packs the
+    pixels it owns (fovpt_gather_pack); the root's unpack of the buffers is the unsharded frame bit for bit (which the
+    full-size tests hold against the oracle), the ranks' ray counts add up to the single-GPU counts, and the shards are balanced."""
+    import torch
+    W, H = size
+    model, probe, camera = scenes.atrium(3800000, material="app"), scenes.ambient_probe(W, H, 2.5), scenes.ATRIUM_CAMERA
+    cfg = cfg_foveated(radii[0], radii[1], (1, 2, 8), max_depth=depth)
+    r = make_gpu(model, probe, camera, (W, H), cfg)
+    r.render()
+    want = r.downloadPixels().copy()
+    written = int((r.downloadAccum()[..., 3] == 1).sum())        # pixels some launch index writes (a few at the borders have none)
+    st = r.stats()
+    full = (st.paths, st.radiance_rays, st.shadow_rays)
+    packed, rays, counts = [], [], None
+    for rank in range(world):
+        c = cfg.copy()
+        c.rank, c.world = rank, world
+        r.config = c
+        r.reset_stats()
+        counts = r.gather_plan()
+        r.launchParams.frame.subframe_index = 0                    # the same frame again (render() advances it, main.cpp:402-407 resets it)
+        r.render()
+        s = r.stats()
+        rays.append((s.paths, s.radiance_rays, s.shadow_rays))
+        stride = (max(counts) + 63) // 64 * 64
+        buf = torch.zeros(stride, dtype=torch.int32, device="cuda")
+        r.gather_pack(r.launchParams.frame.frame_buffer, buf.data_ptr())
+        r.synchronize()
+        packed.append(buf)
+    assert sum(counts) == written and max(counts) - min(counts) < 0.02 * max(counts)
+    assert tuple(sum(x[k] for x in rays) for k in range(3)) == full
+    assert max(x[1] + x[2] for x in rays) < 1.1 * (full[1] + full[2]) / world          # interleaved 8x4 tiles balance the rays
+    c = cfg.copy()
+    c.rank, c.world = 0, world
+    r.config = c
+    r.gather_plan()
+    target = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+    gathered = torch.stack(packed)
+    r.gather_unpack(gathered.data_ptr(), gathered.shape[1], target.data_ptr())
+    r.synchronize()
+    assert np.array_equal(target.cpu().numpy().view(np.uint32).reshape(H, W), want)
+    r.close()
+
+
 @pytest.mark.parametrize("scene", ["atrium"] + (["street"] if os.environ.get("FOVPT_TEST_C5_STREET") == "1" else []))
 def test_c5_stereo_bistro_class_full_size_against_oracle(oracle, scene):
     """BASELINE.json configs[4] at full size on one GPU: ~3.8 M triangles, stereo 2 x 2160x2160 (two cameras
