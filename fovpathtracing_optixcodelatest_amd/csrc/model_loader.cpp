@@ -14,10 +14,12 @@
 //     (v, vn, vt) triple -- the reference's map lives per shape, so a corner first used under an earlier material
 //     keeps the index it got in THAT mesh (a quirk of the reference, kept); textures are looked up per shape too,
 //     so a file named by two shapes is loaded twice
-//   * textures: PNG (all colour types and bit depths, tRNS, Adam7) and binary PPM, as stbi_load returns them with four
-//     channels, then mirrored along y (:117-126).  Anything else counts as "could not load": id -1 (:129-131).
+//   * textures: PNG (all colour types and bit depths, tRNS, Adam7), Truevision TGA (the format of the reference's default
+//     scene: true colour, gray, colour-mapped, run-length forms) and binary PPM, as stbi_load returns them with four
+//     channels, then mirrored along y (:117-126).  Anything else (JPEG, ...) counts as "could not load": id -1 (:129-131).
 #include <zlib.h>
 
+#include <cctype>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -402,6 +404,93 @@ bool decode_ppm(const std::vector<uint8_t>& d, Image& img)       // binary 8-bit
     return true;
 }
 
+// Truevision TGA -> rgba8 the way stb_image reads it: image types 1 / 2 / 3 and their run-length forms 9 / 10 / 11; 8 bits
+// (gray or index), 15 / 16 (5-5-5, or gray + alpha for type 3), 24 and 32; rows bottom-up unless descriptor bit 5 is set;
+// an index past the colour map reads entry 0.  (The texture format of the reference's default scene, main.cpp:196.)
+bool decode_tga(const std::vector<uint8_t>& d, Image& img)
+{
+    if (d.size() < 18) return false;
+    const int idlen = d[0], cmap_type = d[1], itype = d[2];
+    const int cm_first = d[3] | (d[4] << 8), cm_len = d[5] | (d[6] << 8), cm_bits = d[7];
+    const int w = d[12] | (d[13] << 8), h = d[14] | (d[15] << 8), bits = d[16], desc = d[17];
+    const bool rle = itype >= 8;
+    const int base = itype & 7;
+    if (!(base == 1 || base == 2 || base == 3) || w == 0 || h == 0 || cmap_type > 1 || (base == 1) != (cmap_type == 1)) return false;
+    if ((base == 1 && !(bits == 8 || bits == 16)) || (base == 3 && !(bits == 8 || bits == 16)) ||
+        (base == 2 && !(bits == 15 || bits == 16 || bits == 24 || bits == 32))) return false;
+    size_t pos = 18 + (size_t)idlen;
+    auto expand = [](const uint8_t* px, int nbits, bool gray) -> uint32_t {       // one pixel -> rgba8 word
+        uint32_t r, g, b, a = 255;
+        if (nbits == 8) r = g = b = px[0];
+        else if ((nbits == 15 || nbits == 16) && gray) { r = g = b = px[0]; a = px[1]; }
+        else if (nbits == 15 || nbits == 16) {
+            const uint32_t v = px[0] | ((uint32_t)px[1] << 8);
+            r = ((v >> 10) & 31u) * 255u / 31u; g = ((v >> 5) & 31u) * 255u / 31u; b = (v & 31u) * 255u / 31u;
+        } else { r = px[2]; g = px[1]; b = px[0]; if (nbits == 32) a = px[3]; }
+        return r | (g << 8) | (b << 16) | (a << 24);
+    };
+    std::vector<uint32_t> palette;
+    if (cmap_type) {
+        if (!(cm_bits == 8 || cm_bits == 15 || cm_bits == 16 || cm_bits == 24 || cm_bits == 32)) return false;
+        const size_t eb = (size_t)(cm_bits + 7) / 8;
+        pos += (size_t)cm_first;                                   // stb skips "first entry index" BYTES, then reads cm_len entries
+        if (pos + (size_t)cm_len * eb > d.size()) return false;
+        if (base == 1) {
+            palette.resize(cm_len);
+            for (int k = 0; k < cm_len; k++) palette[k] = expand(d.data() + pos + k * eb, cm_bits, false);
+        }
+        pos += (size_t)cm_len * eb;
+    }
+    const size_t nb = (size_t)(bits + 7) / 8, n = (size_t)w * h;
+    std::vector<uint8_t> px(n * nb);
+    if (!rle) {
+        if (pos + n * nb > d.size()) return false;
+        memcpy(px.data(), d.data() + pos, n * nb);
+    } else {
+        size_t got = 0;
+        while (got < n) {
+            if (pos >= d.size()) return false;
+            const int c = d[pos++];
+            const size_t cnt = (size_t)(c & 127) + 1, take = std::min(cnt, n - got);
+            if (c & 128) {
+                if (pos + nb > d.size()) return false;
+                for (size_t k = 0; k < take; k++) memcpy(px.data() + (got + k) * nb, d.data() + pos, nb);
+                pos += nb;
+            } else {
+                if (pos + cnt * nb > d.size()) return false;
+                memcpy(px.data() + got * nb, d.data() + pos, take * nb);
+                pos += cnt * nb;
+            }
+            got += cnt;
+        }
+    }
+    img.w = w; img.h = h;
+    img.px.resize(n);
+    const bool top_down = (desc >> 5) & 1;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const uint8_t* p = px.data() + ((size_t)y * w + x) * nb;
+            uint32_t v;
+            if (base == 1) {
+                size_t idx = nb == 1 ? p[0] : (size_t)(p[0] | (p[1] << 8));
+                if (idx >= (size_t)cm_len) idx = 0;
+                v = palette.empty() ? 0u : palette[idx];
+            } else {
+                v = expand(p, bits, base == 3);
+            }
+            img.px[(size_t)(top_down ? y : h - 1 - y) * w + x] = v;
+        }
+    return true;
+}
+
+bool ends_with_ci(const std::string& s, const char* suffix)
+{
+    const size_t n = strlen(suffix);
+    if (s.size() < n) return false;
+    for (size_t k = 0; k < n; k++) if (tolower((unsigned char)s[s.size() - n + k]) != suffix[k]) return false;
+    return true;
+}
+
 bool load_texture_file(const std::string& path, Image& img)
 {
     std::vector<uint8_t> d;
@@ -409,6 +498,7 @@ bool load_texture_file(const std::string& path, Image& img)
     bool ok = false;
     if (d.size() >= 8 && d[0] == 0x89 && d[1] == 'P') ok = decode_png(d, img);
     else if (d.size() >= 2 && d[0] == 'P' && d[1] == '6') ok = decode_ppm(d, img);
+    else if (ends_with_ci(path, ".tga")) ok = decode_tga(d, img);
     if (!ok) return false;
     for (int y = 0; y < img.h / 2; y++)                                       // mirrored along y, Model.cpp:117-126
         for (int x = 0; x < img.w; x++) std::swap(img.px[(size_t)y * img.w + x], img.px[(size_t)(img.h - 1 - y) * img.w + x]);
@@ -680,7 +770,8 @@ int fovpt_image_load_float4(const char* file, int* width, int* height, fovpt_flo
         bool ok = false;
         if (d.size() >= 8 && d[0] == 0x89 && d[1] == 'P') ok = decode_png(d, img);
         else if (d.size() >= 2 && d[0] == 'P' && d[1] == '6') ok = decode_ppm(d, img);
-        if (!ok) { fovpt_internal_set_error((std::string(file) + ": not an image this loader reads (.hdr, .png, binary .ppm)").c_str()); return FOVPT_E_INVALID; }
+        else if (ends_with_ci(file, ".tga")) ok = decode_tga(d, img);
+        if (!ok) { fovpt_internal_set_error((std::string(file) + ": not an image this loader reads (.hdr, .png, .tga, binary .ppm)").c_str()); return FOVPT_E_INVALID; }
         w = img.w; h = img.h;
         px.resize((size_t)w * h * 4);
         for (size_t q = 0; q < (size_t)w * h; q++) {                         // stbi__ldr_to_hdr: gamma 2.2, scale 1

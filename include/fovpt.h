@@ -309,7 +309,8 @@ int fovpt_camera_uvw(const fovpt_float3* eye, const fovpt_float3* lookat, const 
 #define FOVPT_OP_UNORM8 10  /* ---- Scene ingestion on the host: what loadOBJ returns, PT_sv5_/Model.cpp:138-217 --------------------
  * (with addVertex :49-82 and loadTexture :84-136, i.e. the vendored tinyobjloader with triangulate = true and
  * stbi_load(..., STBI_rgb_alpha) mirrored along y).  Plain host code, no GPU needed.  One mesh per (shape, material id);
- * PNG and binary PPM textures are decoded, any other format counts as "could not load" (texture id -1, as :129-131).
+ * PNG, Truevision TGA and binary PPM textures are decoded, any other format (JPEG, ...) counts as "could not load"
+ * (texture id -1, as :129-131).
  * The arrays stay owned by the model; include/Model.h wraps this as `Model* loadOBJ(const std::string&)`.
  * Errors: FOVPT_E_INVALID, text from fovpt_last_error(NULL) ("Could not read OBJ model from ...", :160-162).          */
 typedef struct fovpt_model fovpt_model;
@@ -329,8 +330,8 @@ int fovpt_model_get_mesh(const fovpt_model* model, int i, fovpt_model_mesh* out)
 int fovpt_model_get_texture(const fovpt_model* model, int i, const uint32_t** pixels, int* width, int* height);
 
 /* The float4 texels loadProbe hands to ProbeData::BuildCDF (PT_sv5_/main.cpp:160-171): what
- * stbi_loadf(file, &w, &h, &n, 4) returns -- Radiance .hdr as it is (RLE and flat scanlines, alpha 1), 8-bit PNG / PPM
- * through stb's gamma-2.2 conversion.  *texels is malloc'ed, width * height entries, row 0 first; release it with
+ * stbi_loadf(file, &w, &h, &n, 4) returns -- Radiance .hdr as it is (RLE and flat scanlines, alpha 1), 8-bit PNG / TGA /
+ * PPM through stb's gamma-2.2 conversion.  *texels is malloc'ed, width * height entries, row 0 first; release it with
  * fovpt_image_free.  Errors: FOVPT_E_INVALID with fovpt_last_error(NULL) (the reference does not check stbi_loadf's
  * result and would build the CDF over a null pointer).                                                               */
 int fovpt_image_load_float4(const char* file, int* width, int* height, fovpt_float4** texels);

@@ -154,3 +154,24 @@ def encode_png(samples: np.ndarray, depth: int, ctype: int, filters=(0, 1, 2, 3,
         out += chunk(b"tRNS", trns)
     half = len(z) // 2
     return out + chunk(b"IDAT", z[:half]) + chunk(b"IDAT", z[half:]) + chunk(b"IEND", b"")
+
+
+# ---- Truevision TGA writer for the loader tests and tests/golden/make_ref_golden.py ----
+def encode_tga(w, h, itype, bits, px_bytes, desc=0, cmap=b"", cm_len=0, cm_bits=0, idfield=b"id"):
+    import struct
+    return struct.pack("<BBBHHBHHHHBB", len(idfield), 1 if cmap else 0, itype, 0, cm_len, cm_bits, 0, 0, w, h, bits, desc) + idfield + cmap + px_bytes
+
+
+def tga_rle(px: np.ndarray) -> bytes:                                # (n, nb) -> alternating run / literal packets
+    out, i, n = bytearray(), 0, len(px)
+    toggle = True
+    while i < n:
+        cnt = min(n - i, 3 if toggle else 5)
+        if toggle:
+            px[i:i + cnt] = px[i]
+            out += bytes([128 | (cnt - 1)]) + px[i].tobytes()
+        else:
+            out += bytes([cnt - 1]) + px[i:i + cnt].tobytes()
+        i += cnt
+        toggle = not toggle
+    return bytes(out)

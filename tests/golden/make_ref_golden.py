@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import ref_cases  # noqa: E402
-from common import encode_hdr_rle, encode_png  # noqa: E402
+from common import encode_hdr_rle, encode_png, encode_tga, tga_rle  # noqa: E402
 
 OBJ = """# three shapes, three materials, quads, negative indices, all corner syntaxes, a texture used by two shapes,
 # a corner shared by two materials of one shape, a (shape, material) whose corners are all known already (its mesh is
@@ -132,6 +132,26 @@ def main():
         "rgb8_adam7.png": encode_png(rng.integers(0, 256, (5, 3, 3)), 8, 2, interlace=True),
     }
     files.update(pngs)
+    # Truevision TGA, the texture format of the reference's default scene (crytek_sponza, main.cpp:196): true colour 24 / 32
+    # bits bottom-up and top-down, run-length packets, gray, gray + alpha, 5-5-5, colour-mapped with indices past the palette
+    tw, th = 7, 5
+    t24, t32 = rng.integers(0, 256, (tw * th, 3), dtype=np.uint8), rng.integers(0, 256, (tw * th, 4), dtype=np.uint8)
+    r24, r32 = rng.integers(0, 256, (tw * th, 3), dtype=np.uint8), rng.integers(0, 256, (tw * th, 4), dtype=np.uint8)
+    g8, ga16 = rng.integers(0, 256, (tw * th, 1), dtype=np.uint8), rng.integers(0, 256, (tw * th, 2), dtype=np.uint8)
+    v555 = rng.integers(0, 1 << 16, tw * th).astype("<u2")
+    pal24 = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    pal_idx = rng.integers(0, 20, (tw * th, 1), dtype=np.uint8)
+    tgas = {
+        "tc24.tga": encode_tga(tw, th, 2, 24, t24.tobytes()),
+        "tc32_top.tga": encode_tga(tw, th, 2, 32, t32.tobytes(), desc=0x28),
+        "rle24.tga": encode_tga(tw, th, 10, 24, tga_rle(r24)),
+        "rle32_top.tga": encode_tga(tw, th, 10, 32, tga_rle(r32), desc=0x20, idfield=b""),
+        "gray8_rle.tga": encode_tga(tw, th, 11, 8, tga_rle(g8), desc=0x20),
+        "gray_alpha16.tga": encode_tga(tw, th, 3, 16, ga16.tobytes()),
+        "rgb555.tga": encode_tga(tw, th, 2, 16, v555.tobytes(), desc=0x20),
+        "pal8.tga": encode_tga(tw, th, 1, 8, pal_idx.tobytes(), cmap=pal24.tobytes(), cm_len=16, cm_bits=24),
+    }
+    files.update(tgas)
     rgbe = rng.integers(0, 256, (6, 16, 4), dtype=np.uint8)
     rgbe[..., 3] = rng.integers(118, 142, (6, 16))
     rgbe[2, :, 0] = 7
@@ -153,7 +173,7 @@ def main():
         assert h, "reference loadOBJ failed"
         lb.update({"obj:" + k: v for k, v in dump_model(L, h).items()})
         L.ref_model_free(h)
-        for name in list(pngs) + ["tex.ppm", "tiles.png"]:
+        for name in list(pngs) + list(tgas) + ["tex.ppm", "tiles.png"]:
             w, hh = C.c_int(0), C.c_int(0)
             assert L.ref_stbi_load(os.path.join(d, name).encode(), C.byref(w), C.byref(hh), None, C.c_size_t(0)), name
             out8 = np.zeros((hh.value, w.value, 4), np.uint8)

@@ -5,6 +5,7 @@ import os
 import numpy as np
 import pytest
 
+from common import encode_tga as _tga, tga_rle as _rle
 from fovpathtracing_optixcodelatest_amd import loaders
 
 OBJ = """# two shapes, two materials, quads, negative indices, all corner syntaxes
@@ -115,7 +116,7 @@ def _expected_texels(rgbe):
 
 
 def test_hdr_rle_scanlines_decode_like_stbi_loadf(tmp_path):
-    from common import encode_hdr_rle
+    from common import encode_hdr_rle, encode_tga as _tga, tga_rle as _rle
     rng = np.random.default_rng(0)
     rgbe = rng.integers(0, 256, (6, 16, 4), dtype=np.uint8)
     rgbe[..., 3] = rng.integers(118, 142, (6, 16))
@@ -317,26 +318,6 @@ def test_png_decoder_rejects_malformed_files():
     for bad in (good[:40], b"\x00" + good[1:], good.replace(b"IDAT", b"iDAT"), good[:16] + b"\x00\x00\x00\x00" + good[20:]):
         with pytest.raises(Exception):
             loaders.decode_png(bad)
-
-
-def _tga(w, h, itype, bits, px_bytes, desc=0, cmap=b"", cm_len=0, cm_bits=0, idfield=b"id"):
-    import struct
-    return struct.pack("<BBBHHBHHHHBB", len(idfield), 1 if cmap else 0, itype, 0, cm_len, cm_bits, 0, 0, w, h, bits, desc) + idfield + cmap + px_bytes
-
-
-def _rle(px: np.ndarray) -> bytes:                                # (n, nb) -> alternating run / literal packets
-    out, i, n = bytearray(), 0, len(px)
-    toggle = True
-    while i < n:
-        cnt = min(n - i, 3 if toggle else 5)
-        if toggle:
-            px[i:i + cnt] = px[i]
-            out += bytes([128 | (cnt - 1)]) + px[i].tobytes()
-        else:
-            out += bytes([cnt - 1]) + px[i:i + cnt].tobytes()
-        i += cnt
-        toggle = not toggle
-    return bytes(out)
 
 
 def test_tga_decoder_truecolour_gray_palette_and_rle():
