@@ -13,7 +13,8 @@ N > 1  : ONE frame is sharded by interleaved launch-index tiles over the ranks (
 
 Prints ONE JSON line on rank 0 (contract in the task description) carrying
   roofline      dominant kernel k_traverse: algorithmic bytes / HIP-event time (the contract's figure), `bound` = what the
-                counters say binds (vector-ALU issue at low lane use, not HBM), `traffic` and `valu` measured IN THIS RUN
+                evidence says binds (the latency of the node step's dependent chain: neither HBM nor the vector ALU, which issues
+                ~40-50 % of its rate), `traffic` and `valu` measured IN THIS RUN
                 by rocprofv3 --pmc child passes of this same script (or, failing that, imported from profiles/ and said so),
                 per-kernel times both overlapped (as the frame runs) and serialised (every kernel alone)
   cpu_baseline  the CPU oracle timed on the host cores on the same frame (N = 1)
@@ -41,7 +42,12 @@ R_INNER, R_OUTER = 148, 482          # the reference's own 2x radii (SimplePatht
 SPP = (1, 2, 8)                      # periphery, middle, fovea
 TARGET_TRIS = 262144
 HBM_PEAK_GBS = 8000.0                # MI355X_MICROARCH.md: HBM3E peak 8 TB/s
-SIMDS, CLOCK_HZ = 1024, 2.4e9        # 256 CUs x 4 SIMDs, 2.4 GHz; one wave-instruction per SIMD every 4 cycles
+SIMDS, CLOCK_HZ = 1024, 2.4e9        # 256 CUs x 4 SIMDs, 2.4 GHz
+# A SIMD issues one wave64 vector instruction per 2 cycles (32 lanes per cycle: 157.3 TFLOP/s fp32 = 1024 SIMDs x 32 x 2 x 2.4 GHz,
+# MI355X_MICROARCH.md); one wave alone gets one per 4.  Measured here with independent fmas at 8 waves per SIMD: 0.98 per ns
+# = 2.45 cycles (tools/micro/valu_rate.hip).  Round 1 and most of round 2 priced issue time at 4 cycles -- twice too much.
+VALU_CYCLES_PER_INST = 2.0
+VALU_MEASURED_INST_PER_NS_PER_SIMD = 0.98
 
 
 def algorithmic_bytes_per_ray(num_tris, kind):
@@ -387,14 +393,16 @@ def main():
         frames_seen = max(1.0, counters.get("k_resolve", {}).get("launches_seen", 3))
         if "SQ_INSTS_VALU" in c:
             lane = c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]) if c.get("SQ_ACTIVE_INST_VALU") else None
-            issue_ms = c["SQ_INSTS_VALU"] * 4.0 / (SIMDS * CLOCK_HZ) * 1e3
+            issue_ms = c["SQ_INSTS_VALU"] * VALU_CYCLES_PER_INST / (SIMDS * CLOCK_HZ) * 1e3
             valu = {
                 "SQ_INSTS_VALU_per_launch": round(c["SQ_INSTS_VALU"]), "lane_use": round(lane, 4) if lane else None,
                 "issue_time_ms_per_launch": round(issue_ms, 5),
                 "issue_frac_of_serialised_launch": round(issue_ms / max(1e-9, c.get("dur_us", 0.0) / 1e3), 4) if c.get("dur_us") else None,
                 "serialised_launch_ms_under_profiler": round(c.get("dur_us", 0.0) / 1e3, 5),
                 "SQ_INSTS_VALU_per_frame_all_kernels": round(tot_inst / frames_seen),
-                "issue_time_ms_per_frame_all_kernels": round(tot_inst / frames_seen * 4.0 / (SIMDS * CLOCK_HZ) * 1e3, 4),
+                "issue_time_ms_per_frame_all_kernels": round(tot_inst / frames_seen * VALU_CYCLES_PER_INST / (SIMDS * CLOCK_HZ) * 1e3, 4),
+                "issue_time_ms_per_frame_at_the_measured_rate": round(tot_inst / frames_seen / (SIMDS * VALU_MEASURED_INST_PER_NS_PER_SIMD) * 1e-6, 4),
+                "issue_rate_note": "one wave64 instruction per SIMD per 2 cycles (spec) / 0.98 per ns (measured, tools/micro/valu_rate.hip)",
                 "per_kernel_lane_use": {k: round(v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 4)
                                         for k, v in counters.items() if v.get("SQ_ACTIVE_INST_VALU")},
             }
@@ -407,10 +415,13 @@ def main():
         except Exception:
             traffic_source = "unavailable: %s" % counters_note
     roofline = {
-        "bound": "valu",
-        "bound_note": "k_traverse is bound by vector-ALU issue at low lane use (16 rays of a wave step in lockstep), not by HBM: the "
-                      "scene stays in L2 / Infinity Cache and `traffic` is a fraction of the algorithmic bytes; `achieved`/`peak`/`frac` "
-                      "are the contract's algorithmic-bytes figure against the 8 TB/s HBM roof, `valu` is what binds",
+        "bound": "latency",
+        "bound_note": "neither roof binds k_traverse: HBM traffic is a sixth of the algorithmic bytes (the scene stays in L2 / Infinity "
+                      "Cache) and the vector ALUs issue ~40-50 % of their rate (`valu`, at low lane use: 16 rays of a wave step in "
+                      "lockstep); what binds is the dependent chain of a node step (load -> box test -> stack -> pop -> load) times "
+                      "the steps per ray at the hardware's 8 waves x 16 rays per SIMD -- DESIGN.md section 4 has the occupancy sweep "
+                      "and the instruction-count, rays-in-flight and node-size experiments that say so; `achieved`/`peak`/`frac` are the "
+                      "contract's algorithmic-bytes figure against the 8 TB/s HBM roof",
         "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
         "avg_launch_ms": round(avg_ms, 5), "avg_launch_ms_serialised": round(avg_ms_serialised, 5),
