@@ -656,12 +656,28 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
     HC(hipMemcpyAsync(h_stats, stats, 8, hipMemcpyDeviceToHost, st));
     HC(hipStreamSynchronize(st));
 
-    out->nodes = nodes; out->tris = tris;
-    out->num_nodes = h_stats[1];
-    out->max_depth = h_stats[0];
-    out->node_bytes = sizeof(BvhNode4) * (size_t)h_stats[1];
-    out->tri_bytes = sizeof(TriRec) * (size_t)n;
-    nodes = nullptr; tris = nullptr;
+    {
+        // The hierarchy that stays: ONE allocation, the nodes actually emitted (the build array is sized for the binary
+        // tree, ~8 x as many) followed by the triangles, so the traversal reaches both through one base register and a
+        // 32-bit offset, and the build's slack goes back to the allocator.
+        const size_t node_bytes = sizeof(BvhNode4) * (size_t)h_stats[1], tri_bytes = sizeof(TriRec) * (size_t)n;
+        const size_t tri_off = (node_bytes + 255) & ~(size_t)255;
+        char* scene = nullptr;
+        HC(hipMalloc(&scene, tri_off + tri_bytes + 64));          // + slack: a lane may fetch 16 bytes past its record
+        if (hipMemcpyAsync(scene, nodes, node_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess
+            || hipMemcpyAsync(scene + tri_off, tris, tri_bytes, hipMemcpyDeviceToDevice, st) != hipSuccess
+            || hipMemsetAsync(scene + tri_off + tri_bytes, 0, 64, st) != hipSuccess
+            || hipStreamSynchronize(st) != hipSuccess) {
+            (void)hipFree(scene);
+            snprintf(err, errlen, "copying the hierarchy failed");
+            goto fail;
+        }
+        out->nodes = (BvhNode4*)scene; out->tris = (TriRec*)(scene + tri_off);      // tris is INSIDE the nodes allocation
+        out->num_nodes = h_stats[1];
+        out->max_depth = h_stats[0];
+        out->node_bytes = node_bytes;
+        out->tri_bytes = tri_bytes;
+    }
 fail:
     if (err[0]) rc = hipErrorUnknown;
     (void)hipFree(boxes); (void)hipFree(ibox); (void)hipFree(bounds); (void)hipFree(stats); (void)hipFree(keys); (void)hipFree(keys_s);

@@ -173,8 +173,7 @@ void drain_events(fovpt_ctx* c)
 
 void free_scene(fovpt_ctx* c)
 {
-    if (c->nodes) (void)hipFree(c->nodes);
-    if (c->tris) (void)hipFree(c->tris);
+    if (c->nodes) (void)hipFree(c->nodes);          // (the triangles live in the same allocation, behind the nodes)
     c->nodes = nullptr; c->tris = nullptr;
     for (void* p : c->tex_pixels) (void)hipFree(p);
     c->tex_pixels.clear();
@@ -275,6 +274,7 @@ int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passe
             const uint32_t rows_per = (uint32_t)(budget / per_row);
             for (uint32_t y0 = 0; y0 < P.gh; y0 += rows_per) {
                 PassDev Q = P;
+                Q.frame_pass = (uint32_t)p;        // the job holds ONE pass; ownership still rotates with its place in the frame
                 Q.row0 = y0; Q.row1 = y0 + rows_per < P.gh ? y0 + rows_per : P.gh;
                 int rc = run_job(c, lp, &Q, 1, 1, 0);
                 if (rc) return rc;
@@ -283,7 +283,7 @@ int run_passes(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passe
         return FOVPT_OK;
     }
     PassDev full[FOVPT_MAX_PASSES];
-    for (int p = 0; p < npass; p++) { full[p] = passes_in[p]; full[p].row0 = 0; full[p].row1 = passes_in[p].gh; }
+    for (int p = 0; p < npass; p++) { full[p] = passes_in[p]; full[p].row0 = 0; full[p].row1 = passes_in[p].gh; full[p].frame_pass = (uint32_t)p; }
     c->stats.frames++;
     return run_job(c, lp, full, npass, 0, whole_frame);
 }
@@ -365,6 +365,7 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     sc.nodes = c->nodes; sc.tris = c->tris; sc.tri_tc = (const float2*)c->tri_tc.p;
     sc.meshes = (const MeshDev*)c->meshes.p; sc.textures = (const TexDev*)c->textures.p;
     sc.num_tris = c->num_tris; sc.any_catcher = c->any_catcher;
+    sc.tri_off = (uint32_t)((const char*)c->tris - (const char*)c->nodes);
     Counters* cnt = (Counters*)S.counters.p;
     RayQueue qa, qb;
     qa.o = (float4*)S.q_o[0].p; qa.d = (float4*)S.q_d[0].p;
@@ -639,12 +640,13 @@ int fovpt_set_scene(fovpt_ctx* c, const fovpt_mesh_desc* meshes, int num_meshes,
     (void)hipEventElapsedTime(&ms, e0, e1);
     if (be != hipSuccess) return fail(c, FOVPT_E_DEVICE, "LBVH build: %s", errbuf);
     if (3 * br.max_depth + 1 > FOVPT_STACK) {       // a wide node leaves at most 3 entries behind
-        (void)hipFree(br.nodes); (void)hipFree(br.tris);
+        (void)hipFree(br.nodes);
         return fail(c, FOVPT_E_BVH_DEPTH, "hierarchy depth %u needs more than the %d traversal stack entries", br.max_depth, FOVPT_STACK);
     }
-    if (br.node_bytes >= (1ull << 32) || br.tri_bytes >= (1ull << 32)) {
-        (void)hipFree(br.nodes); (void)hipFree(br.tris);
-        return fail(c, FOVPT_E_INVALID, "hierarchy of %llu bytes exceeds the 32-bit offsets of the traversal", (unsigned long long)br.node_bytes);
+    if ((size_t)((const char*)br.tris - (const char*)br.nodes) + br.tri_bytes + 64 >= (1ull << 32)) {
+        (void)hipFree(br.nodes);
+        return fail(c, FOVPT_E_INVALID, "hierarchy of %llu bytes exceeds the 32-bit offsets of the traversal",
+                    (unsigned long long)(br.node_bytes + br.tri_bytes));
     }
     c->nodes = br.nodes; c->tris = br.tris;
     c->num_tris = (uint32_t)ntri;
@@ -843,7 +845,7 @@ int fovpt_gather_plan(fovpt_ctx* c, const fovpt_launch_params* lp, uint32_t* cou
         FrameDev fd;
         memset(&fd, 0, sizeof(fd));
         fd.npass = frame_passes(c->cfg, L, P);
-        for (int p = 0; p < fd.npass; p++) { fd.pass[p] = P[p]; fd.pass[p].row0 = 0; fd.pass[p].row1 = P[p].gh; }
+        for (int p = 0; p < fd.npass; p++) { fd.pass[p] = P[p]; fd.pass[p].row0 = 0; fd.pass[p].row1 = P[p].gh; fd.pass[p].frame_pass = (uint32_t)p; }
         fd.w = L.frame.size.x; fd.h = L.frame.size.y;
         fd.cx = L.frame.c.x; fd.cy = L.frame.c.y;
         fd.rank = c->cfg.rank; fd.world = world;

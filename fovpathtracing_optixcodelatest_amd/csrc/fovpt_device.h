@@ -12,6 +12,9 @@
 #ifndef FOVPT_V_STEPSTAT
 #define FOVPT_V_STEPSTAT 0         // 1: diagnostic build (tools/stepstat.py, tools/raystat.py)
 #endif
+#ifndef FOVPT_V_CYCLES
+#define FOVPT_V_CYCLES 0           // 1: diagnostic build with s_memtime stamps inside the traversal steps (tools/stepcycles.py)
+#endif
 #ifndef FOVPT_LEAF_MAX
 #define FOVPT_LEAF_MAX 4          // triangles per BVH leaf (<= 8: three bits in the leaf code)
 #endif
@@ -63,12 +66,13 @@ struct MeshDev {                  // the SBT record of the reference (LaunchPara
 
 struct SceneView {
     const BvhNode4* nodes;
-    const TriRec* tris;           // leaf order
+    const TriRec* tris;           // leaf order; lives in the nodes' allocation, tri_off bytes behind `nodes`
     const float2* tri_tc;         // 3 per global primitive id (or null)
     const MeshDev* meshes;
     const TexDev* textures;
     uint32_t num_tris;
     uint32_t any_catcher;
+    uint32_t tri_off;             // (const char*)tris - (const char*)nodes: one base register reaches both
 };
 
 
@@ -84,7 +88,8 @@ struct PassDev {                  // one optixLaunch worth of parameters
     uint32_t slot_base;           // first sample slot of this pass
     uint32_t launch_base;         // first launch record of this pass
     uint32_t row0, row1;          // launch rows [row0, row1) handled by this job (a chunk of a large launch)
-    uint32_t pad;
+    uint32_t frame_pass;          // index of this launch within the caller's frame (P 0, M 1, F 2): the tile ownership of
+                                  // launch_owned() rotates with it, also when the launch runs as a job of its own (chunks)
 };
 
 struct FrameDev {
@@ -160,6 +165,11 @@ struct Counters {       // device-resident, zeroed per frame except the stats bl
     // diagnostics of a -DFOVPT_V_STEPSTAT=1 build (tools/stepstat.py): per ray kind [closest, any-hit]
     // wave-level node steps, active quads in them, wave-level leaf steps, active quads in them
     unsigned long long diag[2][4];
+#if FOVPT_V_CYCLES
+    // diagnostics of a -DFOVPT_V_CYCLES=1 build (tools/stepcycles.py): s_memtime ticks (shader cycles) summed per wave
+    unsigned long long cyc[2][8][16];   // [ray kind][iteration & 7][field], fields: see struct Cyc in wavefront.hip
+    uint32_t hist[2][8][3][64];         // [kind][iteration & 7][node load wait /16 | node step /32 | leaf step /32][bin]
+#endif
 };
 static_assert(2 * (FOVPT_MAX_ITERS + 1) <= FOVPT_SHARD_STRIDE, "shard block holds both queues' sizes");
 #define FOVPT_CNT_Q(it) (it)                               // word index inside a shard's block
@@ -167,7 +177,7 @@ static_assert(2 * (FOVPT_MAX_ITERS + 1) <= FOVPT_SHARD_STRIDE, "shard block hold
 
 // ---- launchers implemented in wavefront.hip / bvh_build.hip -------------------------------
 struct BvhBuildResult {
-    BvhNode4* nodes;
+    BvhNode4* nodes;              // ONE allocation: the emitted nodes, then (256-byte aligned) the triangles; free `nodes` only
     TriRec* tris;
     uint32_t num_nodes;           // wide nodes emitted (breadth-first order, root = 0)
     uint32_t max_depth;

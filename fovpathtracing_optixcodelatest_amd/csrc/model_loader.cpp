@@ -27,6 +27,8 @@
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <new>
+#include <exception>
 #include <memory>
 #include <set>
 #include <sstream>
@@ -310,6 +312,18 @@ bool decode_png(const std::vector<uint8_t>& d, Image& img)
         } while (rc != Z_STREAM_END);
         inflateEnd(&zs);
     }
+    {   // the inflated stream must hold every scanline the header promises before buffers of the header's size are allocated
+        size_t need = 0;
+        if (!interlace) need = (((size_t)w * chans * depth + 7) / 8 + 1) * (size_t)h;
+        else {
+            static const int P7[7][4] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+            for (const auto& a : P7) {
+                const long pw = ((long)w - a[0] + a[2] - 1) / a[2], ph = ((long)h - a[1] + a[3] - 1) / a[3];
+                if (pw > 0 && ph > 0) need += (((size_t)pw * chans * depth + 7) / 8 + 1) * (size_t)ph;
+            }
+        }
+        if (raw.size() < need) return false;
+    }
     std::vector<uint16_t> smp((size_t)w * h * chans, 0);
     auto put = [&](const std::vector<uint8_t>& rows, int pw, int ph, size_t rowbytes, int x0, int y0, int dx, int dy) {
         for (int y = 0; y < ph; y++) {
@@ -394,7 +408,9 @@ bool decode_ppm(const std::vector<uint8_t>& d, Image& img)       // binary 8-bit
         pos = end + 1;
     }
     const long w = strtol(toks[1].c_str(), nullptr, 10), h = strtol(toks[2].c_str(), nullptr, 10), mx = strtol(toks[3].c_str(), nullptr, 10);
-    if (toks[0] != "P6" || mx != 255 || w <= 0 || h <= 0 || pos + (size_t)w * h * 3 > d.size()) return false;
+    // sizes are bounded BEFORE any arithmetic on them (a 64-bit w * h * 3 wraps): 2^24 per side, 2^28 pixels, as for PNG
+    if (toks[0] != "P6" || mx != 255 || w <= 0 || h <= 0 || w > (1l << 24) || h > (1l << 24)) return false;
+    if ((uint64_t)w * (uint64_t)h > (1ull << 28) || (uint64_t)w * (uint64_t)h * 3ull > (uint64_t)(d.size() - pos)) return false;
     img.w = (int)w; img.h = (int)h;
     img.px.resize((size_t)w * h);
     for (size_t p = 0; p < (size_t)w * h; p++) {
@@ -442,6 +458,10 @@ bool decode_tga(const std::vector<uint8_t>& d, Image& img)
         pos += (size_t)cm_len * eb;
     }
     const size_t nb = (size_t)(bits + 7) / 8, n = (size_t)w * h;
+    // the file must be able to hold the image before anything is allocated for it: n pixels raw, or at least one packet
+    // byte per 128 pixels run-length encoded
+    if (pos > d.size()) return false;
+    if (!rle ? n * nb > d.size() - pos : (n + 127) / 128 > d.size() - pos) return false;
     std::vector<uint8_t> px(n * nb);
     if (!rle) {
         if (pos + n * nb > d.size()) return false;
@@ -608,9 +628,25 @@ struct fovpt_model {
     std::vector<Image> textures;
 };
 
+// No C++ exception leaves the C ABI: a failed allocation (bad_alloc, length_error) or anything else thrown while a file is
+// read becomes an error code and fovpt_last_error(NULL), not std::terminate in the host application.
+template <typename F> static int guarded(const char* what, F&& body)
+{
+    try { return body(); }
+    catch (const std::bad_alloc&) { fovpt_internal_set_error((std::string(what) + ": out of memory").c_str()); return FOVPT_E_NOMEM; }
+    catch (const std::exception& e) { fovpt_internal_set_error((std::string(what) + ": " + e.what()).c_str()); return FOVPT_E_INVALID; }
+    catch (...) { fovpt_internal_set_error((std::string(what) + ": unknown failure").c_str()); return FOVPT_E_INVALID; }
+}
+
 extern "C" {
 
+static int model_load_obj_impl(const char* obj_file, fovpt_model** out);
 int fovpt_model_load_obj(const char* obj_file, fovpt_model** out)
+{
+    if (out) *out = nullptr;
+    return guarded("fovpt_model_load_obj", [&]() { return model_load_obj_impl(obj_file, out); });
+}
+static int model_load_obj_impl(const char* obj_file, fovpt_model** out)
 {
     if (!obj_file || !out) { fovpt_internal_set_error("fovpt_model_load_obj: null argument"); return FOVPT_E_INVALID; }
     *out = nullptr;
@@ -754,7 +790,13 @@ int fovpt_model_get_texture(const fovpt_model* m, int i, const uint32_t** pixels
     return FOVPT_OK;
 }
 
+static int image_load_float4_impl(const char* file, int* width, int* height, fovpt_float4** texels);
 int fovpt_image_load_float4(const char* file, int* width, int* height, fovpt_float4** texels)
+{
+    if (texels) *texels = nullptr;
+    return guarded("fovpt_image_load_float4", [&]() { return image_load_float4_impl(file, width, height, texels); });
+}
+static int image_load_float4_impl(const char* file, int* width, int* height, fovpt_float4** texels)
 {
     if (!file || !width || !height || !texels) { fovpt_internal_set_error("fovpt_image_load_float4: null argument"); return FOVPT_E_INVALID; }
     *texels = nullptr;

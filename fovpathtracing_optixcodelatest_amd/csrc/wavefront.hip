@@ -527,11 +527,13 @@ struct ShardMap {
     }
 };
 
+// p: index of the pass within this JOB; the rotation uses its index within the caller's FRAME (a chunked frame runs every
+// pass as jobs of its own, and the gather plan is made for the frame)
 __device__ inline bool launch_owned(const FrameDev& fd, int p, uint32_t lx, uint32_t ly)
 {
     if (fd.world <= 1) return true;
     uint32_t tx = lx / (uint32_t)fd.tile_w, ty = ly / (uint32_t)fd.tile_h;
-    return (int)((tx + 3u * ty + (uint32_t)p) % (uint32_t)fd.world) == fd.rank;
+    return (int)((tx + 3u * ty + fd.pass[p].frame_pass) % (uint32_t)fd.world) == fd.rank;
 }
 
 // ring test of deviceProgram.cu:433-440 on the block's top-left pixel (uint arithmetic wraps)
@@ -720,13 +722,51 @@ __device__ inline void stepstat(unsigned long long* diag)
 #define STEPSTAT(d)
 #endif
 
+#if FOVPT_V_CYCLES
+// Diagnostic build: s_memtime stamps (shader cycles) inside the steps.  A stamp is tied to the registers whose arrival it
+// marks (asm operands), so the compiler's own waits sit in front of it.  Everything here is wave-uniform and lives in
+// SGPRs; the histograms are in LDS.  The stamps themselves cost a wave ~10 % (MI355X_MICROARCH.md): read the SHARES.
+struct Cyc {
+    uint32_t last;                                   // stamp at the end of the previous step (or of the ray's setup)
+    uint32_t n_node, gap, load, alu, lds;            // node steps: loop overhead | issue -> data | box test + rank | write + pop
+    uint32_t n_leaf, lgap, lload, lrest;             // leaf steps
+    __device__ inline void init() { n_node = gap = load = alu = lds = n_leaf = lgap = lload = lrest = 0u; last = 0u; }
+};
+__shared__ uint32_t s_cyc_hist[3 * 64];               // node load wait /16 | node step /32 | leaf step /32
+__device__ inline uint32_t cyc_stamp()
+{ unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory"); return (uint32_t)t; }
+template <typename A> __device__ inline uint32_t cyc_stamp(A& a)
+{ unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "+v"(a) : : "memory"); return (uint32_t)t; }
+template <typename A, typename B> __device__ inline uint32_t cyc_stamp(A& a, B& b)
+{ unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "+v"(a), "+v"(b) : : "memory"); return (uint32_t)t; }
+__device__ inline void cyc_hist(uint32_t* h, uint32_t bin)      // FOVPT_V_CYCLES=2 only: ~25 scalar instructions per step
+{
+    if (FOVPT_V_CYCLES < 2) return;
+    const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
+    if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ex)) atomicAdd(h + min(bin, 63u), 1u);
+}
+#define CYC_P , Cyc& C
+#define CYC_A , C
+#else
+#define CYC_P
+#define CYC_A
+#endif
+
 // wide internal node: lane j owns child j
 template <bool ANY_HIT>
-__device__ inline void node_step(const SceneView& sc, const RayT& r, const QuadLane& q, QuadTrav& T)
+__device__ inline void node_step(const SceneView& sc, const RayT& r, const QuadLane& q, QuadTrav& T CYC_P)
 {
+#if FOVPT_V_CYCLES
+    const uint32_t c0 = cyc_stamp(T.cur);
+#endif
     // uniform base + 32-bit offset (fovpt_set_scene keeps nodes and triangles below 4 GB)
     const float4* np = (const float4*)((const char*)sc.nodes + (((uint32_t)T.cur << 7) | q.j32));
+#if FOVPT_V_CYCLES
+    float4 a = np[0], b = np[1];
+    const uint32_t c1 = cyc_stamp(a.x, b.z);
+#else
     const float4 a = np[0], b = np[1];
+#endif
     const int code = __float_as_int(b.z);
     float t;
     const bool h = box_hit(r, a.x, a.y, a.z, a.w, b.x, b.y, TMIN, T.lim, t);
@@ -752,21 +792,42 @@ __device__ inline void node_step(const SceneView& sc, const RayT& r, const QuadL
         const int lt = ((int)(quad_rot1(key) - key) >> 31) + ((int)(quad_rot2(key) - key) >> 31) + ((int)(quad_rot3(key) - key) >> 31);
         row = (lt << 8) + 3 * ROWB;             // 3 - (number of keys below mine)
     }
+#if FOVPT_V_CYCLES
+    const uint32_t c2 = cyc_stamp(row, Hm1);
+#endif
     *(int*)(T.top + row) = code;
     T.top += Hm1 * ROWB;                        // H pushed, one popped
     __builtin_amdgcn_wave_barrier();
     T.cur = *(const int*)T.top;
+#if FOVPT_V_CYCLES
+    const uint32_t c3 = cyc_stamp(T.cur);
+    C.n_node++; C.gap += c0 - C.last; C.load += c1 - c0; C.alu += c2 - c1; C.lds += c3 - c2;
+    cyc_hist(s_cyc_hist, (c1 - c0) >> 4);
+    cyc_hist(s_cyc_hist + 64, (c3 - C.last) >> 5);
+    C.last = c3;
+#endif
 }
 
 // leaf: lane j owns triangle j (branch-free: the four lanes of 16 rays never agree on an early out).
 // A lane beyond the leaf's count repeats triangle 0: the duplicate candidate changes nothing.
 // Any-hit: returns true when a front-facing triangle was hit (the ray is occluded, nothing is popped).
 template <bool ANY_HIT>
-__device__ inline bool leaf_step(const SceneView& sc, const RayT& r, const QuadLane& q, QuadTrav& T)
+__device__ inline bool leaf_step(const SceneView& sc, const RayT& r, const QuadLane& q, QuadTrav& T CYC_P)
 {
+#if FOVPT_V_CYCLES
+    const uint32_t c0 = cyc_stamp(T.cur);
+#endif
     const uint32_t lcode = (uint32_t)~T.cur;
     const uint32_t tri16 = (lcode >> 3) + (q.j <= (lcode & 7u) ? q.j3 : 0u);     // in 16-byte units
+#if FOVPT_V_CYCLES
+    TriRec R = load_tri_off(sc.tris, tri16 << 4);
+    const uint32_t c1 = cyc_stamp(R.v0x, R.e2z);
+#define CYC_LEAF_END(x) { const uint32_t c2 = cyc_stamp(x); C.n_leaf++; C.lgap += c0 - C.last; C.lload += c1 - c0; C.lrest += c2 - c1; \
+                          cyc_hist(s_cyc_hist + 128, (c2 - C.last) >> 5); C.last = c2; }
+#else
     const TriRec R = load_tri_off(sc.tris, tri16 << 4);
+#define CYC_LEAF_END(x)
+#endif
     const V3 d = v3(r.dx, r.dy, r.dz);
     const V3 e1 = v3(R.e1x, R.e1y, R.e1z), e2 = v3(R.e2x, R.e2y, R.e2z);
     const V3 p = cross(d, e2);
@@ -782,7 +843,7 @@ __device__ inline bool leaf_step(const SceneView& sc, const RayT& r, const QuadL
     const bool ok = (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > TMIN) & (t < TMAX);
     if (ANY_HIT) {
         // front face: counter-clockwise seen from the origin
-        if ((uint32_t)(__builtin_amdgcn_ballot_w64(ok & (det > 0.0f)) >> q.qshift) & 15u) return true;
+        if ((uint32_t)(__builtin_amdgcn_ballot_w64(ok & (det > 0.0f)) >> q.qshift) & 15u) { CYC_LEAF_END(T.cur); return true; }
     } else {
         const bool better = ok & ((t < T.bt) | ((t == T.bt) & (R.prim < T.bprim)));
         T.bt = better ? t : T.bt; T.bu = better ? u : T.bu; T.bv = better ? v : T.bv;
@@ -795,6 +856,7 @@ __device__ inline bool leaf_step(const SceneView& sc, const RayT& r, const QuadL
     }
     T.top -= ROWB;
     T.cur = *(const int*)T.top;
+    CYC_LEAF_END(T.cur);
     return false;
 }
 
@@ -831,9 +893,12 @@ __device__ inline void store_shadow(const PathState& ps, const ShadowQueue& sq, 
 // ballot (one shift), every lane stores its child at a row derived from its rank and the next node is
 // simply popped -- descending and backtracking are the same code, no cross-lane selects.
 __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __restrict__ stack /* [e * QUADS_PER_BLOCK] */, const QuadLane& q,
-                              QuadTrav& T, unsigned long long* diag)
+                              QuadTrav& T, unsigned long long* diag CYC_P)
 {
     T.start(stack, q);
+#if FOVPT_V_CYCLES
+    C.last = cyc_stamp(T.cur);
+#endif
 #if FOVPT_V_STEPSTAT
     // (no arrays with a run-time index here: a diagnostic build whose traversal kernel used scratch memory faulted with
     // HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on the closest-hit launch; the product kernels use none)
@@ -841,22 +906,91 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
     T.tr_lo = T.tr_hi = 0ull; T.n0 = 0u;
     for (;;) {
         uint32_t ph = 0;
-        while (T.cur >= 0) { STEPSTAT(diag); node_step<false>(sc, r, q, T); nn++; ph++; }
+        while (T.cur >= 0) { STEPSTAT(diag); node_step<false>(sc, r, q, T CYC_A); nn++; ph++; }
         { const unsigned long long v = (unsigned long long)min(ph, 255u) << ((nl & 7u) * 8u); if (nl < 8u) T.tr_lo |= v; else if (nl < 15u) T.tr_hi |= v; }
         if (T.cur == TRAV_DONE) break;
         STEPSTAT(diag + 2);
-        leaf_step<false>(sc, r, q, T); nl++;
+        leaf_step<false>(sc, r, q, T CYC_A); nl++;
     }
     T.steps = nn | (nl << 16);
     T.tr_hi |= (unsigned long long)min(T.n0, 255u) << 56;
 #else
     for (;;) {
-        while (T.cur >= 0) node_step<false>(sc, r, q, T);
+        while (T.cur >= 0) node_step<false>(sc, r, q, T CYC_A);
         if (T.cur == TRAV_DONE) return;
-        leaf_step<false>(sc, r, q, T);
+        leaf_step<false>(sc, r, q, T CYC_A);
     }
 #endif
 }
+
+#ifndef FOVPT_V_IFIF
+#define FOVPT_V_IFIF 0
+#endif
+#if FOVPT_V_IFIF
+// "if-if" form of the closest-hit traversal: ONE loop whose every pass lets each quad do whatever its ray needs next -- a
+// node test or a leaf test -- behind ONE wait for memory (nodes and triangles are reached through one base register, so the
+// pass issues one set of loads for all quads).  In the while-while form above a ray that has reached a leaf waits until the
+// last ray of the wave has left the node phase (measured: of 12.3 rays alive in an average node step only 6.5 step), and
+// every leaf phase is a memory round trip of its own.
+__device__ inline void traverse_quad_ifif(const SceneView& sc, const RayT& r, int* __restrict__ stack, const QuadLane& q, QuadTrav& T)
+{
+    T.start(stack, q);
+    const char* base = (const char*)sc.nodes;
+    while (T.cur != TRAV_DONE) {
+        const bool leaf = T.cur < 0;
+        uint32_t off = ((uint32_t)T.cur << 7) | q.j32;
+        uint32_t tri16 = 0u;
+        float4 c;
+        if (leaf) {
+            const uint32_t lcode = (uint32_t)~T.cur;
+            tri16 = (lcode >> 3) + (q.j <= (lcode & 7u) ? q.j3 : 0u);     // in 16-byte units
+            off = sc.tri_off + (tri16 << 4);
+            c = *(const float4*)(base + off + 32);
+        }
+        const float4 a = *(const float4*)(base + off), b = *(const float4*)(base + off + 16);
+        if (!leaf) {
+            // ---- node_step<false>
+            const int code = __float_as_int(b.z);
+            float t;
+            const bool h = box_hit(r, a.x, a.y, a.z, a.w, b.x, b.y, TMIN, T.lim, t);
+            const uint32_t m4 = (uint32_t)(__builtin_amdgcn_ballot_w64(h) >> q.qshift) & 15u;
+            int Hm1;                                    // (b.w rides along unused: both parts then read ONE full 16-byte load of b)
+            asm("v_bcnt_u32_b32 %0, %1, -1" : "=v"(Hm1) : "v"(m4), "v"(b.w));
+            uint32_t key;
+            asm("v_and_or_b32 %0, %1, -4, %2" : "=v"(key) : "v"(h ? __float_as_uint(t) : 0u), "v"(q.j));
+            const int lt = ((int)(quad_rot1(key) - key) >> 31) + ((int)(quad_rot2(key) - key) >> 31) + ((int)(quad_rot3(key) - key) >> 31);
+            const int row = (lt << 8) + 3 * ROWB;
+            *(int*)(T.top + row) = code;
+            T.top += Hm1 * ROWB;
+            __builtin_amdgcn_wave_barrier();
+            T.cur = *(const int*)T.top;
+        } else {
+            // ---- leaf_step<false>
+            const V3 d = v3(r.dx, r.dy, r.dz);
+            const V3 e1 = v3(a.w, b.x, b.y), e2 = v3(b.z, b.w, c.x);
+            const uint32_t prim = __float_as_uint(c.y);
+            const V3 p = cross(d, e2);
+            const float det = dot(e1, p);
+            const float inv = 1.0f / det;
+            const V3 sv = v3(r.ox, r.oy, r.oz) - v3(a.x, a.y, a.z);
+            const float u = dot(sv, p) * inv;
+            const V3 qq = cross(sv, e1);
+            const float v = dot(d, qq) * inv;
+            const float t = dot(e2, qq) * inv;
+            const bool ok = (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > TMIN) & (t < TMAX);
+            const bool better = ok & ((t < T.bt) | ((t == T.bt) & (prim < T.bprim)));
+            T.bt = better ? t : T.bt; T.bu = better ? u : T.bu; T.bv = better ? v : T.bv;
+            T.bpos = better ? tri16 : T.bpos; T.bprim = better ? prim : T.bprim;
+            uint32_t m = __float_as_uint(T.bt);
+            m = min(m, quad_rot2(m));
+            m = min(m, quad_rot1(m));
+            T.lim = fminf(TMAX, __uint_as_float(m) * 1.000001f);
+            T.top -= ROWB;
+            T.cur = *(const int*)T.top;
+        }
+    }
+}
+#endif
 
 // Any-hit traversal over a POOL of shadow rays [first, end) owned by one wave: a quad that has finished
 // its ray takes the next one of the pool as soon as FOVPT_REFILL quads of the wave are idle (all of them
@@ -868,11 +1002,14 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
 #define FOVPT_REFILL 6
 #endif
 __device__ inline void traverse_shadow_pool(const SceneView& sc, const PathState& ps, const ShadowQueue& sq, const ShardMap& map, uint32_t cap,
-                                            uint32_t first, uint32_t end, int* __restrict__ stack, const QuadLane& q, unsigned long long* diag)
+                                            uint32_t first, uint32_t end, int* __restrict__ stack, const QuadLane& q, unsigned long long* diag CYC_P)
 {
     QuadTrav T;
     T.start(stack, q);
     T.cur = TRAV_DONE;
+#if FOVPT_V_CYCLES
+    C.last = cyc_stamp(T.cur);
+#endif
     RayT r = {};
     uint32_t ph = 0;                              // physical index of the quad's shadow record
     bool pending = false, occluded = false;
@@ -895,12 +1032,15 @@ __device__ inline void traverse_shadow_pool(const SceneView& sc, const PathState
                 }
             }
             next = min(end, next + n_idle);
+#if FOVPT_V_CYCLES
+            C.last = cyc_stamp(T.cur);
+#endif
             if (n_idle == 16u && __builtin_amdgcn_ballot_w64(T.cur != TRAV_DONE) == 0ull) return;      // pool exhausted, all results stored
         }
-        while (T.cur >= 0) { STEPSTAT(diag); node_step<true>(sc, r, q, T); }
+        while (T.cur >= 0) { STEPSTAT(diag); node_step<true>(sc, r, q, T CYC_A); }
         if (T.cur != TRAV_DONE) {
             STEPSTAT(diag + 2);
-            if (leaf_step<true>(sc, r, q, T)) { occluded = true; T.cur = TRAV_DONE; }
+            if (leaf_step<true>(sc, r, q, T CYC_A)) { occluded = true; T.cur = TRAV_DONE; }
         }
     }
 }
@@ -926,12 +1066,25 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
     }
     QuadLane q;
     q.init();
+#if FOVPT_V_CYCLES
+    uint32_t stack_byte = threadIdx.x & ~3u;          // opaque copies: the flush at the end rebuilds the thread index from
+    asm volatile("" : "+v"(stack_byte), "+v"(q.j), "+v"(q.qshift));     // values that are live anyway (no spill, no scratch)
+    int* stack = (int*)((char*)s_stack + stack_byte);
+#else
     int* stack = s_stack + (threadIdx.x >> 2);
+#endif
+#if FOVPT_V_CYCLES
+    if (threadIdx.x < 192) s_cyc_hist[threadIdx.x] = 0u;
+    __syncthreads();
+    Cyc C; C.init();
+    const uint32_t life0 = cyc_stamp();
+    const unsigned long long real0 = __builtin_amdgcn_s_memrealtime();
+#endif
     // occlusion rays: every wave owns one contiguous pool
     if (n_sh) {
         const uint32_t nwaves = gridDim.x * (FOVPT_BLOCK / 64), wave = blockIdx.x * (FOVPT_BLOCK / 64) + (threadIdx.x >> 6);
         const uint32_t per = (n_sh + nwaves - 1u) / nwaves, first = min(n_sh, wave * per);
-        traverse_shadow_pool(sc, ps, sq, ms, cap, first, min(n_sh, first + per), stack, q, cnt->diag[1]);
+        traverse_shadow_pool(sc, ps, sq, ms, cap, first, min(n_sh, first + per), stack, q, cnt->diag[1] CYC_A);
     }
     // closest-hit rays: static grid-stride over quads, 16 consecutive rays per wave and round
     const uint32_t quads = gridDim.x * FOVPT_QUADS_PER_BLOCK;
@@ -942,7 +1095,11 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
         const uint32_t ph = mq.phys16(i, i0, cap);
         const float4 o = queue.o[ph], d = queue.d[ph];
         ray_setup(r, o, d);
-        traverse_quad(sc, r, stack, q, T, cnt->diag[0]);
+#if FOVPT_V_IFIF
+        traverse_quad_ifif(sc, r, stack, q, T);
+#else
+        traverse_quad(sc, r, stack, q, T, cnt->diag[0] CYC_A);
+#endif
         store_hit(ps, ph, T);
 #if FOVPT_V_STEPSTAT
         if (q.j == 0) {                                                   // tools/raystat.py, raytrace_dump.py
@@ -951,6 +1108,25 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
         }
 #endif
     }
+#if FOVPT_V_CYCLES
+    {
+        const uint32_t life1 = cyc_stamp();
+        const unsigned long long real1 = __builtin_amdgcn_s_memrealtime();
+        const int kind = it_shadow >= 0 ? 1 : 0, itn = (it_shadow >= 0 ? it_shadow : it_closest) & 7;
+        unsigned long long* g = cnt->cyc[kind][itn];
+        if ((q.qshift | q.j) == 0u) {
+            const uint32_t x = cyc_stamp(), y = cyc_stamp();      // two stamps back to back: what a stamp costs
+            const uint32_t v[14] = {C.n_node, C.gap, C.load, C.alu, C.lds, C.n_leaf, C.lgap, C.lload, C.lrest, y - x, 1u,
+                                    life1 - life0, (uint32_t)(real1 - real0), 1u};
+#pragma unroll
+            for (int k = 0; k < 14; k++) atomicAdd(g + k, (unsigned long long)v[k]);
+        }
+        __syncthreads();
+        // (the thread index rebuilt from values that are live through the loops: the build stays free of scratch)
+        const uint32_t tid = stack_byte | q.j;
+        if (tid < 192 && s_cyc_hist[tid]) atomicAdd(&cnt->hist[kind][itn][tid >> 6][tid & 63u], s_cyc_hist[tid]);
+    }
+#endif
 }
 
 // ---- shade -------------------------------------------------------------------------------
@@ -1437,7 +1613,7 @@ __device__ inline uint32_t launch_owner_rank(const FrameDev& fd, int p, uint32_t
 {
     if (fd.world <= 1) return 0u;
     const uint32_t tx = lx / (uint32_t)fd.tile_w, ty = ly / (uint32_t)fd.tile_h;
-    return (tx + 3u * ty + (uint32_t)p) % (uint32_t)fd.world;
+    return (tx + 3u * ty + fd.pass[p].frame_pass) % (uint32_t)fd.world;
 }
 // owner[pixel] and, per block of 256 consecutive pixels, the number of pixels every rank owns
 __global__ __launch_bounds__(FOVPT_BLOCK) void k_plan_owner(const FrameDev fd, uint8_t* __restrict__ owner, uint32_t* __restrict__ block_count)

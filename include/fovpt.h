@@ -295,18 +295,7 @@ int fovpt_camera_uvw(const fovpt_float3* eye, const fovpt_float3* lookat, const 
                      float fovY_degrees, float aspect,
                      fovpt_float3* U, fovpt_float3* V, fovpt_float3* W);
 
-/* ---- device self-test hook (tests only): evaluates one scalar function on the GPU
- * for n inputs; op codes FOVPT_OP_*.  a,b host arrays (b may be NULL), out host.  */
-#define FOVPT_OP_SIN    1
-#define FOVPT_OP_COS    2
-#define FOVPT_OP_ACOS   3
-#define FOVPT_OP_ATAN2  4
-#define FOVPT_OP_LOG    5
-#define FOVPT_OP_POW    6
-#define FOVPT_OP_SQRT   7
-#define FOVPT_OP_DIV    8
-#define FOVPT_OP_RSQRTD 9   /* (float)(1.0 / (double)sqrtf(a)), maths.h:98 */
-#define FOVPT_OP_UNORM8 10  /* ---- Scene ingestion on the host: what loadOBJ returns, PT_sv5_/Model.cpp:138-217 --------------------
+/* ---- Scene ingestion on the host: what loadOBJ returns, PT_sv5_/Model.cpp:138-217 --------------------
  * (with addVertex :49-82 and loadTexture :84-136, i.e. the vendored tinyobjloader with triangulate = true and
  * stbi_load(..., STBI_rgb_alpha) mirrored along y).  Plain host code, no GPU needed.  One mesh per (shape, material id);
  * PNG, Truevision TGA and binary PPM textures are decoded, any other format (JPEG, ...) counts as "could not load"
@@ -337,7 +326,18 @@ int fovpt_model_get_texture(const fovpt_model* model, int i, const uint32_t** pi
 int fovpt_image_load_float4(const char* file, int* width, int* height, fovpt_float4** texels);
 void fovpt_image_free(fovpt_float4* texels);
 
-/* texel channel (uint8)a / 255.0f as the shading kernel computes it */
+/* ---- device self-test hook (tests only): evaluates one scalar function on the GPU
+ * for n inputs; op codes FOVPT_OP_*.  a,b host arrays (b may be NULL), out host.  */
+#define FOVPT_OP_SIN    1
+#define FOVPT_OP_COS    2
+#define FOVPT_OP_ACOS   3
+#define FOVPT_OP_ATAN2  4
+#define FOVPT_OP_LOG    5
+#define FOVPT_OP_POW    6
+#define FOVPT_OP_SQRT   7
+#define FOVPT_OP_DIV    8
+#define FOVPT_OP_RSQRTD 9   /* (float)(1.0 / (double)sqrtf(a)), maths.h:98 */
+#define FOVPT_OP_UNORM8 10  /* texel channel (uint8)a / 255.0f as the shading kernel computes it */
 int fovpt_debug_math(fovpt_ctx* ctx, int op, const float* a, const float* b, float* out, size_t n);
 /* tests/diagnostics only: device address and size of an internal buffer ("sq_occ", "counters", "hit", "bvh_nodes", ...) */
 int fovpt_debug_buffer(fovpt_ctx* ctx, const char* name, void** ptr, size_t* bytes);

@@ -429,6 +429,49 @@ def test_packed_gather_plan_pack_unpack(world):
     root.close()
 
 
+@pytest.mark.parametrize("world", [2, 5])
+def test_packed_gather_of_a_chunked_frame(world, monkeypatch):
+    """above the slot budget every pass of a frame runs as jobs of its own, and the tile ownership of
+    the middle and fovea passes must still rotate with the pass's place in the FRAME (the gather plan is made for the
+    frame): pack / unpack of chunked, sharded frames is the unsharded, unchunked frame."""
+    import torch
+    size = (200, 120)
+    W, H = size
+    model, probe = scenes.atrium(6000), scenes.sky_probe()
+    cfg = cfg_foveated(14, 44, (1, 2, 4))
+    gaze = (90, 70)
+    full = make_gpu(model, probe, scenes.ATRIUM_CAMERA, size, cfg, gaze=gaze)
+    full.render()
+    want = full.downloadPixels()
+    full.close()
+    monkeypatch.setenv("FOVPT_SLOT_BUDGET", "700")            # >= one launch row of every pass (50, 92, 120 slots), << a pass
+    packed, root, plans = [], None, []
+    for rank in range(world):
+        c = cfg.copy()
+        c.rank, c.world = rank, world
+        r = make_gpu(model, probe, scenes.ATRIUM_CAMERA, size, c, gaze=gaze)
+        counts = r.gather_plan()
+        plans.append(counts)
+        r.render()
+        stride = (max(counts) + 63) // 64 * 64
+        buf = torch.full((stride,), -1, dtype=torch.int32, device="cuda")
+        r.gather_pack(r.launchParams.frame.frame_buffer, buf.data_ptr())
+        r.synchronize()
+        packed.append(buf.cpu())
+        if rank == 0:
+            root = r
+        else:
+            r.close()
+    assert all(p == plans[0] for p in plans)
+    gathered = torch.stack(packed).to("cuda")
+    target = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+    root.gather_unpack(gathered.data_ptr(), packed[0].numel(), target.data_ptr())
+    root.synchronize()
+    root.close()
+    got = target.cpu().numpy().view(np.uint32).reshape(H, W)
+    assert np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("options", [abi.OPT_SKY_MISS, abi.OPT_RUSSIAN_ROULETTE, abi.OPT_SKY_MISS | abi.OPT_RUSSIAN_ROULETTE])
 def test_opt_in_extensions_match_the_oracle(oracle, options):
     """fovpt_config.options: sky radiance for escaped secondary rays (the MIS counterpart PT_sv5_ carries commented out,

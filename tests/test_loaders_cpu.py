@@ -369,3 +369,55 @@ def test_obj_with_png_and_tga_textures(tmp_path):
     tb = t.reshape(6, 4, 3).astype(np.uint32)                        # bottom-up file -> stb flips -> Model.cpp mirrors back
     px = model.textures[1]
     assert np.array_equal(px, tb[..., 2] | (tb[..., 1] << 8) | (tb[..., 0] << 16) | (255 << 24))
+
+
+def test_oversized_image_headers_under_asan(tmp_path):
+    """headers that promise more pixels than the file holds -- or than any arithmetic on them survives
+    without wrapping -- are rejected before anything is allocated or indexed; no exception leaves the C ABI.  The loader is
+    compiled with AddressSanitizer for this, so an out-of-bounds access fails the test even when it would not crash."""
+    import struct, subprocess, zlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "loader_asan"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer", "-ffp-contract=off",
+                           os.path.join(root, "fovpathtracing_optixcodelatest_amd", "csrc", "model_loader.cpp"),
+                           os.path.join(root, "tests", "cpp", "loader_asan_main.cpp"), "-lz", "-o", str(exe)])
+    files = {}
+    # PPM: w * h * 3 wraps a 64-bit size_t (the file ADVICE r2 names), and plain huge sizes
+    files["wrap.ppm"] = b"P6\n3 6148914691236517206\n255\n" + bytes(6)
+    files["huge.ppm"] = b"P6\n70000 70000\n255\n" + bytes(64)
+    files["side.ppm"] = b"P6\n16777217 1\n255\n" + bytes(64)
+    files["neg.ppm"] = b"P6\n-4 -4\n255\n" + bytes(64)
+    # PNG: a 2^14 x 2^14 RGBA16 header (2 GB of samples) over 32 inflated bytes
+    def chunk(kind, body):
+        return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xffffffff)
+    sig = b"\x89PNG\r\n\x1a\n"
+    files["huge.png"] = sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 1 << 14, 1 << 14, 16, 6, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(bytes(32))) + chunk(b"IEND", b"")
+    files["huge_adam7.png"] = sig + chunk(b"IHDR", struct.pack(">IIBBBBB", 1 << 14, 1 << 14, 8, 2, 0, 0, 1)) + chunk(b"IDAT", zlib.compress(bytes(32))) + chunk(b"IEND", b"")
+    files["side.png"] = sig + chunk(b"IHDR", struct.pack(">IIBBBBB", (1 << 24) + 1, 1, 8, 0, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(bytes(32))) + chunk(b"IEND", b"")
+    # TGA: 65535 x 65535 x 32 bits, raw and run-length encoded, over a few bytes of data
+    def tga(itype, w, h, bits, data):
+        return bytes([0, 0, itype, 0, 0, 0, 0, 0, 0, 0, 0, 0, w & 255, w >> 8, h & 255, h >> 8, bits, 0]) + data
+    files["huge_raw.tga"] = tga(2, 65535, 65535, 32, bytes(16))
+    files["huge_rle.tga"] = tga(10, 65535, 65535, 32, bytes([0xff, 1, 2, 3, 4]) * 3)
+    # a small valid PPM still loads (the test would otherwise pass on a loader that rejects everything)
+    files["ok.ppm"] = b"P6\n2 2\n255\n" + bytes(range(12))
+    # and the same files as textures of an OBJ (the y-flip loop of load_texture_file is where the PPM overflow hit)
+    for name in ("wrap.ppm", "huge.png", "huge_raw.tga"):
+        base = name.replace(".", "_")
+        files[base + ".mtl"] = ("newmtl m\nKd 1 1 1\nmap_Kd %s\n" % name).encode()
+        files[base + ".obj"] = ("mtllib %s.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 0 1\nusemtl m\nf 1/1 2/2 3/3\n" % base).encode()
+    for n, b in files.items():
+        (tmp_path / n).write_bytes(b)
+    names = [n for n in files if not n.endswith(".mtl")]
+    res = subprocess.run([str(exe)] + [str(tmp_path / n) for n in names], capture_output=True, text=True,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:allocator_may_return_null=1"))
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = {os.path.basename(l.split()[0]): l for l in res.stdout.splitlines()}
+    assert len(out) == len(names), res.stdout
+    for n in names:
+        if n == "ok.ppm":
+            assert "rc=0 2x2" in out[n], out[n]
+        elif n.endswith(".obj"):
+            assert "rc=0 meshes=1 textures=0" in out[n], out[n]        # a texture that cannot be read is id -1, Model.cpp:129-131
+        else:
+            assert "rc=0" not in out[n], out[n]

@@ -1,0 +1,83 @@
+"""Diagnostic: where the cycles of a traversal step go (needs a -DFOVPT_V_CYCLES=1|2 build, FOVPT_SO=...).
+
+The build stamps s_memtime (shader cycles) inside node_step / leaf_step of k_traverse:
+  node step:  gap (loop overhead since the previous step) | load (address -> both 16-byte loads arrived)
+              | alu (box test, hit mask, rank) | lds (stack write, wave barrier, pop)
+  leaf step:  gap | load (triangle record arrived) | rest (Moeller-Trumbore, merge, pop)
+and sums them per wave (all values are wave-level: a wave steps its 16 rays in lockstep).  With FOVPT_V_CYCLES=2 it also
+fills histograms of the load wait and of whole steps.  The stamps cost a wave ~10 %: read the shares, not the totals.
+
+usage: FOVPT_SO=build/libfovpt_cyc1.so python tools/stepcycles.py [atrium|street] [frames]"""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from fovpathtracing_optixcodelatest_amd import abi, renderer, scenes, lib
+
+W, H = 1920, 1080
+which = sys.argv[1] if len(sys.argv) > 1 else "atrium"
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+street = which == "street"
+ntri = int(os.environ.get("FOVPT_TRIS", "3800000" if street else "262144"))
+model = scenes.street(ntri) if street else scenes.atrium(ntri)
+r = renderer.SampleRenderer(model); r.resize((W, H))
+cam = scenes.STREET_CAMERA if street else scenes.ATRIUM_CAMERA
+r.setCamera(renderer.Camera(cam["eye"], cam["lookat"], cam["up"], cam["fovy"], W / H))
+r.setProbe(renderer.ProbeData(scenes.sky_probe(512, 256, seed=5) if street else scenes.ambient_probe(W, H, 2.5)).BuildCDF())
+cfg = abi.Config.reference_default(); cfg.r_inner, cfg.r_outer = 148, 482
+cfg.spp_periphery, cfg.spp_middle, cfg.spp_fovea = 1, 2, 8
+cfg.max_depth = int(os.environ.get("FOVPT_DEPTH", "4"))
+cfg.profile = int(os.environ.get("FOVPT_PROFILE", "2"))        # 2: every kernel alone (no overlap between the two streams)
+r.config = cfg
+r.launchParams.frame.c.x, r.launchParams.frame.c.y = W // 2, H // 2
+for _ in range(2):
+    r.launchParams.frame.subframe_index = 0
+    r.render()
+r.reset_stats()
+L = lib.load()
+BASE = 8 * 128 * 4 + 3 * 8 + 2 * 4 * 8
+cyc = np.zeros((2, 8, 16), np.uint64)
+hist = np.zeros((2, 8, 3, 64), np.uint64)
+seen = set()
+for f in range(frames):
+    r.launchParams.frame.subframe_index = 0
+    r.render()
+    p, n = C.c_void_p(), C.c_size_t()
+    lib.check(r._ctx, L.fovpt_debug_buffer(r._ctx, b"counters", C.byref(p), C.byref(n)))
+    last = (p.value, n.value)
+    seen.add(last)
+st = r.stats()
+for (ptr, n) in seen:          # the two state sets accumulate separately since reset_stats()
+    raw = np.empty(n, np.uint8)
+    r.download(ptr, raw)
+    assert n >= BASE + cyc.nbytes + 2 * 8 * 3 * 64 * 4, "not a FOVPT_V_CYCLES build (counters block is %d bytes)" % n
+    cyc += raw[BASE:BASE + cyc.nbytes].view(np.uint64).reshape(cyc.shape)
+    hist += raw[BASE + cyc.nbytes:BASE + cyc.nbytes + 2 * 8 * 3 * 64 * 4].view(np.uint32).reshape(hist.shape)
+print("scene %s, %d triangles, %d frame(s), profile %d; rays/frame: closest %d, any-hit %d"
+      % (which, model.num_triangles, frames, cfg.profile, st.radiance_rays // frames, st.shadow_rays // frames))
+print("ms/frame serialised: closest %.3f any-hit %.3f shade %.3f" % (st.ms_trace / frames, st.ms_shadow / frames, st.ms_shade / frames))
+names = ("closest", "any-hit")
+for k in range(2):
+    for it in range(8):
+        v = [float(x) for x in cyc[k, it]]
+        n_node, gap, load, alu, lds, n_leaf, lgap, lload, lrest, cal, ncal, life, real, waves = v[:14]
+        if waves == 0 or n_node == 0:
+            continue
+        clock = life / (real / 100e6) / 1e9 if real else float("nan")        # s_memrealtime ticks at 100 MHz
+        node = gap + load + alu + lds
+        leaf = lgap + lload + lrest
+        print("%-7s it %d | waves/frame %6d  clock %.2f GHz  wave life %7.0f cyc (%.1f us)  in steps %4.1f %%  stamp %3.0f cyc"
+              % (names[k], it, waves / frames, clock, life / waves, life / waves / clock / 1e3, 100 * (node + leaf) / life, cal / max(ncal, 1)))
+        print("          node steps/wave %6.1f  cyc/step %6.0f = gap %4.0f + load %4.0f + alu %4.0f + lds %4.0f   (%.0f / %.0f / %.0f / %.0f %%)"
+              % (n_node / waves, node / n_node, gap / n_node, load / n_node, alu / n_node, lds / n_node,
+                 100 * gap / node, 100 * load / node, 100 * alu / node, 100 * lds / node))
+        if n_leaf:
+            print("          leaf steps/wave %6.1f  cyc/step %6.0f = gap %4.0f + load %4.0f + rest %4.0f" % (n_leaf / waves, leaf / n_leaf, lgap / n_leaf, lload / n_leaf, lrest / n_leaf))
+        for hi, (hname, width) in enumerate((("node load wait", 16), ("node step", 32), ("leaf step", 32))):
+            h = hist[k, it, hi].astype(np.float64)
+            if h.sum() == 0:
+                continue
+            c = np.cumsum(h) / h.sum()
+            q = [int(np.searchsorted(c, x)) * width for x in (0.1, 0.5, 0.9, 0.99)]
+            print("          hist %-14s p10 %5d  p50 %5d  p90 %5d  p99 %5d cyc (bins of %d; last bin = overflow: %.1f %%)" % (hname, *q, width, 100 * h[-1] / h.sum()))
+            if os.environ.get("FOVPT_HIST_FULL"):
+                print("            " + " ".join("%d" % x for x in h))
