@@ -11,6 +11,8 @@
 #include <vector>
 
 #include "fovpt_device.h"
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // types only: the library is loaded at run time (fovpt_comm_*), libfovpt.so does not link it
 
 namespace {
 
@@ -86,6 +88,10 @@ struct fovpt_ctx {
     std::vector<uint32_t> plan_off;        // host copy: rank r owns plan_idx[plan_off[r] .. plan_off[r + 1])
     std::string plan_key;                  // what the plan was built for
     bool use_accum_before = false;
+    // RCCL transport of the packed gather (fovpt_comm_init / fovpt_gather_frame)
+    ncclComm_t comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
+    DevBuf comm_packed, comm_gathered;
     // Wavefront state, TWO sets used alternately by consecutive jobs: the tail of job k (its last occlusion
     // rays and its resolve, on the shadow stream) runs beside the head of job k+1 (generate, camera rays)
     StateSet set[2];
@@ -535,10 +541,12 @@ void fovpt_destroy(fovpt_ctx* c)
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
         for (DevBuf* b : S.all()) b->release();
     }
+    (void)fovpt_comm_destroy(c);
     free_scene(c);
     DevBuf* bufs[] = {&c->tri_tc, &c->meshes, &c->textures, &c->pr_data, &c->pr_pdfx, &c->pr_cdfx, &c->pr_pdfy, &c->pr_cdfy, &c->pr_guidex, &c->pr_guidey, &c->pr_rec,
                       &c->fb_frame, &c->fb_accum, &c->fb_color, &c->fb_normal, &c->fb_albedo, &c->accum_before,
-                      &c->plan_owner, &c->plan_blocks, &c->plan_total, &c->plan_base, &c->plan_idx};
+                      &c->plan_owner, &c->plan_blocks, &c->plan_total, &c->plan_base, &c->plan_idx,
+                      &c->comm_packed, &c->comm_gathered};
     for (DevBuf* b : bufs) b->release();
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->shadow_stream) (void)hipStreamDestroy(c->shadow_stream);
@@ -898,6 +906,128 @@ int fovpt_gather_unpack(fovpt_ctx* c, const uint32_t* gathered, uint32_t stride,
         if (c->plan_off[r + 1] - c->plan_off[r] > stride) return fail(c, FOVPT_E_INVALID, "stride %u is smaller than rank %d's %u pixels", stride, r, c->plan_off[r + 1] - c->plan_off[r]);
     fovpt_launch_gather_unpack(c->shadow_stream, world, stride, c->plan_off[world], (const uint32_t*)c->plan_base.p, (const uint32_t*)c->plan_idx.p, gathered, frame);
     HIPCHK(c, hipGetLastError());
+    return FOVPT_OK;
+}
+
+// ---- multi-GPU: the transport between pack and unpack, RCCL over xGMI, for C / C++ hosts ----------------------------
+// One process (or thread) per GPU, each with its own fovpt_ctx; the gather of a frame is
+//   plan -> pack (HIP) -> ncclGroupStart; ncclSend to the root; on the root ncclRecv from every rank; ncclGroupEnd -> unpack
+// all enqueued on fovpt_stream(), the stream frames complete on: no host synchronisation, and the transport of frame k runs
+// beside the rendering of frame k + 1.  librccl is loaded at run time so that libfovpt.so has no link-time dependency on it
+// (a process that already holds an RCCL -- PyTorch's -- gets that one: same SONAME).
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    bool tried = false;
+    std::string why;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+Rccl& rccl()
+{
+    static Rccl R;
+    if (R.tried) return R;
+    R.tried = true;
+    const char* names[] = {getenv("FOVPT_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names) {
+        if (!n || !*n) continue;
+        R.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (R.lib) break;
+        R.why = dlerror() ? dlerror() : "dlopen failed";
+    }
+    if (!R.lib) { if (R.why.empty()) R.why = "librccl not found"; return R; }
+    struct { const char* n; void** f; } syms[] = {
+        {"ncclGetUniqueId", (void**)&R.GetUniqueId}, {"ncclCommInitRank", (void**)&R.CommInitRank}, {"ncclCommDestroy", (void**)&R.CommDestroy},
+        {"ncclGroupStart", (void**)&R.GroupStart}, {"ncclGroupEnd", (void**)&R.GroupEnd}, {"ncclSend", (void**)&R.Send}, {"ncclRecv", (void**)&R.Recv},
+        {"ncclGetErrorString", (void**)&R.GetErrorString}};
+    for (auto& sy : syms) {
+        *sy.f = dlsym(R.lib, sy.n);
+        if (!*sy.f) { R.why = std::string("librccl lacks ") + sy.n; dlclose(R.lib); R.lib = nullptr; return R; }
+    }
+    return R;
+}
+#define NCCLCHK(c, x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return fail((c), FOVPT_E_DEVICE, "%s: %s", #x, rccl().GetErrorString(r_)); } while (0)
+}  // namespace
+
+int fovpt_comm_get_unique_id(void* id)
+{
+    if (!id) return fail(nullptr, FOVPT_E_INVALID, "fovpt_comm_get_unique_id: null argument");
+    Rccl& R = rccl();
+    if (!R.lib) return fail(nullptr, FOVPT_E_DEVICE, "RCCL is not available: %s", R.why.c_str());
+    static_assert(FOVPT_COMM_ID_BYTES == sizeof(ncclUniqueId), "unique id size");
+    ncclUniqueId u;
+    NCCLCHK(nullptr, R.GetUniqueId(&u));
+    memcpy(id, &u, sizeof(u));
+    return FOVPT_OK;
+}
+
+int fovpt_comm_init(fovpt_ctx* c, const void* id, int rank, int world)
+{
+    if (!c || !id) return FOVPT_E_INVALID;
+    if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail(c, FOVPT_E_INVALID, "bad rank %d of %d (1 .. 64 ranks)", rank, world);
+    Rccl& R = rccl();
+    if (!R.lib) return fail(c, FOVPT_E_DEVICE, "RCCL is not available: %s", R.why.c_str());
+    int rc = fovpt_comm_destroy(c);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    NCCLCHK(c, R.CommInitRank(&c->comm, world, u, rank));      // collective: every rank calls it, each on its own device
+    c->comm_rank = rank; c->comm_world = world;
+    return FOVPT_OK;
+}
+
+int fovpt_comm_destroy(fovpt_ctx* c)
+{
+    if (!c) return FOVPT_E_INVALID;
+    if (!c->comm) return FOVPT_OK;
+    (void)hipSetDevice(c->device);
+    if (c->shadow_stream) (void)hipStreamSynchronize(c->shadow_stream);
+    ncclComm_t comm = c->comm;
+    c->comm = nullptr; c->comm_world = 0;
+    NCCLCHK(c, rccl().CommDestroy(comm));
+    return FOVPT_OK;
+}
+
+int fovpt_gather_frame(fovpt_ctx* c, const fovpt_launch_params* lp, int root, const uint32_t* frame, uint32_t* full_frame)
+{
+    if (!c || !lp || !frame) return FOVPT_E_INVALID;
+    if (!c->comm) return fail(c, FOVPT_E_INVALID, "fovpt_gather_frame without a communicator (fovpt_comm_init)");
+    const int world = c->comm_world, rank = c->comm_rank;
+    if (c->cfg.world != world || c->cfg.rank != rank)
+        return fail(c, FOVPT_E_INVALID, "the communicator is rank %d of %d, fovpt_config says %d of %d", rank, world, c->cfg.rank, c->cfg.world);
+    if (root < 0 || root >= world) return fail(c, FOVPT_E_INVALID, "bad root %d", root);
+    if (rank == root && !full_frame) return fail(c, FOVPT_E_INVALID, "the root needs a frame to gather into");
+    uint32_t counts[64];
+    int rc = fovpt_gather_plan(c, lp, counts, 64);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    uint32_t stride = 0;
+    for (int r = 0; r < world; r++) stride = counts[r] > stride ? counts[r] : stride;
+    stride = (stride + 63u) & ~63u;
+    if (stride == 0) return FOVPT_OK;                               // no launch index writes any pixel
+    HIPCHK(c, c->comm_packed.reserve((size_t)stride * 4));
+    if (rank == root) HIPCHK(c, c->comm_gathered.reserve((size_t)stride * 4 * world));
+    rc = fovpt_gather_pack(c, frame, (uint32_t*)c->comm_packed.p);
+    if (rc) return rc;
+    Rccl& R = rccl();
+    hipStream_t st = c->shadow_stream;
+    NCCLCHK(c, R.GroupStart());
+    if (rank == root)
+        for (int r = 0; r < world; r++)
+            if (counts[r]) NCCLCHK(c, R.Recv((uint32_t*)c->comm_gathered.p + (size_t)r * stride, counts[r], ncclUint32, r, c->comm, st));
+    if (counts[rank]) NCCLCHK(c, R.Send(c->comm_packed.p, counts[rank], ncclUint32, root, c->comm, st));
+    NCCLCHK(c, R.GroupEnd());
+    if (rank == root) {
+        rc = fovpt_gather_unpack(c, (const uint32_t*)c->comm_gathered.p, stride, full_frame);
+        if (rc) return rc;
+    }
     return FOVPT_OK;
 }
 

@@ -169,6 +169,7 @@ struct Counters {       // device-resident, zeroed per frame except the stats bl
     // diagnostics of a -DFOVPT_V_CYCLES=1 build (tools/stepcycles.py): s_memtime ticks (shader cycles) summed per wave
     unsigned long long cyc[2][8][16];   // [ray kind][iteration & 7][field], fields: see struct Cyc in wavefront.hip
     uint32_t hist[2][8][3][64];         // [kind][iteration & 7][node load wait /16 | node step /32 | leaf step /32][bin]
+    unsigned long long wtime[8][8192][2];   // [kind * 4 + iteration & 3][wave]: s_memrealtime (100 MHz) at the wave's start and end
 #endif
 };
 static_assert(2 * (FOVPT_MAX_ITERS + 1) <= FOVPT_SHARD_STRIDE, "shard block holds both queues' sizes");

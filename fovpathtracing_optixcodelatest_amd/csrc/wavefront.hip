@@ -723,15 +723,14 @@ __device__ inline void stepstat(unsigned long long* diag)
 #endif
 
 #if FOVPT_V_CYCLES
-// Diagnostic build: s_memtime stamps (shader cycles) inside the steps.  A stamp is tied to the registers whose arrival it
-// marks (asm operands), so the compiler's own waits sit in front of it.  Everything here is wave-uniform and lives in
-// SGPRs; the histograms are in LDS.  The stamps themselves cost a wave ~10 % (MI355X_MICROARCH.md): read the SHARES.
-struct Cyc {
-    uint32_t last;                                   // stamp at the end of the previous step (or of the ray's setup)
-    uint32_t n_node, gap, load, alu, lds;            // node steps: loop overhead | issue -> data | box test + rank | write + pop
-    uint32_t n_leaf, lgap, lload, lrest;             // leaf steps
-    __device__ inline void init() { n_node = gap = load = alu = lds = n_leaf = lgap = lload = lrest = 0u; last = 0u; }
-};
+// Diagnostic build: s_memtime stamps (shader cycles) inside the steps of a SAMPLE of the waves -- wave 0 of the first 256
+// blocks, about one wave per CU.  (Stamping every wave makes the launch 4-8 x slower: 8192 waves x 4 stamps per step is
+// more than the timestamp path serves, and the time lands in whatever segment a wave happens to wait in.)  A stamp is tied
+// to the registers whose arrival it marks (asm operands), so the compiler's own waits sit in front of it.  The sums are
+// WAVE-level: the first active lane of a step adds them to a per-block LDS record (a variable carried through the
+// divergent step loops would be per lane).  FOVPT_V_CYCLES=2 adds histograms.
+struct Cyc { bool on; };
+__shared__ uint32_t s_cyc_acc[16];                    // 0 n_node, 1 gap, 2 load, 3 alu, 4 lds, 5 n_leaf, 6 lgap, 7 lload, 8 lrest, 15 last stamp
 __shared__ uint32_t s_cyc_hist[3 * 64];               // node load wait /16 | node step /32 | leaf step /32
 __device__ inline uint32_t cyc_stamp()
 { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory"); return (uint32_t)t; }
@@ -739,12 +738,9 @@ template <typename A> __device__ inline uint32_t cyc_stamp(A& a)
 { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "+v"(a) : : "memory"); return (uint32_t)t; }
 template <typename A, typename B> __device__ inline uint32_t cyc_stamp(A& a, B& b)
 { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t), "+v"(a), "+v"(b) : : "memory"); return (uint32_t)t; }
-__device__ inline void cyc_hist(uint32_t* h, uint32_t bin)      // FOVPT_V_CYCLES=2 only: ~25 scalar instructions per step
-{
-    if (FOVPT_V_CYCLES < 2) return;
-    const unsigned long long ex = __builtin_amdgcn_ballot_w64(true);
-    if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(ex)) atomicAdd(h + min(bin, 63u), 1u);
-}
+__device__ inline bool cyc_first_lane()
+{ return (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true)); }
+__device__ inline void cyc_hist(uint32_t* h, uint32_t bin) { if (FOVPT_V_CYCLES >= 2) atomicAdd(h + min(bin, 63u), 1u); }
 #define CYC_P , Cyc& C
 #define CYC_A , C
 #else
@@ -757,13 +753,14 @@ template <bool ANY_HIT>
 __device__ inline void node_step(const SceneView& sc, const RayT& r, const QuadLane& q, QuadTrav& T CYC_P)
 {
 #if FOVPT_V_CYCLES
-    const uint32_t c0 = cyc_stamp(T.cur);
+    uint32_t c0 = 0, c1 = 0, c2 = 0;
+    if (C.on) c0 = cyc_stamp(T.cur);
 #endif
     // uniform base + 32-bit offset (fovpt_set_scene keeps nodes and triangles below 4 GB)
     const float4* np = (const float4*)((const char*)sc.nodes + (((uint32_t)T.cur << 7) | q.j32));
 #if FOVPT_V_CYCLES
     float4 a = np[0], b = np[1];
-    const uint32_t c1 = cyc_stamp(a.x, b.z);
+    if (C.on) c1 = cyc_stamp(a.x, b.z);
 #else
     const float4 a = np[0], b = np[1];
 #endif
@@ -793,18 +790,24 @@ __device__ inline void node_step(const SceneView& sc, const RayT& r, const QuadL
         row = (lt << 8) + 3 * ROWB;             // 3 - (number of keys below mine)
     }
 #if FOVPT_V_CYCLES
-    const uint32_t c2 = cyc_stamp(row, Hm1);
+    if (C.on) c2 = cyc_stamp(row, Hm1);
 #endif
     *(int*)(T.top + row) = code;
     T.top += Hm1 * ROWB;                        // H pushed, one popped
     __builtin_amdgcn_wave_barrier();
     T.cur = *(const int*)T.top;
 #if FOVPT_V_CYCLES
-    const uint32_t c3 = cyc_stamp(T.cur);
-    C.n_node++; C.gap += c0 - C.last; C.load += c1 - c0; C.alu += c2 - c1; C.lds += c3 - c2;
-    cyc_hist(s_cyc_hist, (c1 - c0) >> 4);
-    cyc_hist(s_cyc_hist + 64, (c3 - C.last) >> 5);
-    C.last = c3;
+    if (C.on) {
+        const uint32_t c3 = cyc_stamp(T.cur);
+        if (cyc_first_lane()) {
+            const uint32_t last = s_cyc_acc[15];
+            atomicAdd(&s_cyc_acc[0], 1u); atomicAdd(&s_cyc_acc[1], c0 - last); atomicAdd(&s_cyc_acc[2], c1 - c0);
+            atomicAdd(&s_cyc_acc[3], c2 - c1); atomicAdd(&s_cyc_acc[4], c3 - c2);
+            cyc_hist(s_cyc_hist, (c1 - c0) >> 4);
+            cyc_hist(s_cyc_hist + 64, (c3 - last) >> 5);
+            s_cyc_acc[15] = cyc_stamp();               // (the bookkeeping itself stays out of the next step's gap)
+        }
+    }
 #endif
 }
 
@@ -815,15 +818,17 @@ template <bool ANY_HIT>
 __device__ inline bool leaf_step(const SceneView& sc, const RayT& r, const QuadLane& q, QuadTrav& T CYC_P)
 {
 #if FOVPT_V_CYCLES
-    const uint32_t c0 = cyc_stamp(T.cur);
+    uint32_t c0 = 0, c1 = 0;
+    if (C.on) c0 = cyc_stamp(T.cur);
 #endif
     const uint32_t lcode = (uint32_t)~T.cur;
     const uint32_t tri16 = (lcode >> 3) + (q.j <= (lcode & 7u) ? q.j3 : 0u);     // in 16-byte units
 #if FOVPT_V_CYCLES
     TriRec R = load_tri_off(sc.tris, tri16 << 4);
-    const uint32_t c1 = cyc_stamp(R.v0x, R.e2z);
-#define CYC_LEAF_END(x) { const uint32_t c2 = cyc_stamp(x); C.n_leaf++; C.lgap += c0 - C.last; C.lload += c1 - c0; C.lrest += c2 - c1; \
-                          cyc_hist(s_cyc_hist + 128, (c2 - C.last) >> 5); C.last = c2; }
+    if (C.on) c1 = cyc_stamp(R.v0x, R.e2z);
+#define CYC_LEAF_END(x) if (C.on) { const uint32_t c2 = cyc_stamp(x); if (cyc_first_lane()) { const uint32_t last = s_cyc_acc[15]; \
+        atomicAdd(&s_cyc_acc[5], 1u); atomicAdd(&s_cyc_acc[6], c0 - last); atomicAdd(&s_cyc_acc[7], c1 - c0); atomicAdd(&s_cyc_acc[8], c2 - c1); \
+        cyc_hist(s_cyc_hist + 128, (c2 - last) >> 5); s_cyc_acc[15] = cyc_stamp(); } }
 #else
     const TriRec R = load_tri_off(sc.tris, tri16 << 4);
 #define CYC_LEAF_END(x)
@@ -897,7 +902,7 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
 {
     T.start(stack, q);
 #if FOVPT_V_CYCLES
-    C.last = cyc_stamp(T.cur);
+    if (C.on && cyc_first_lane()) s_cyc_acc[15] = cyc_stamp();
 #endif
 #if FOVPT_V_STEPSTAT
     // (no arrays with a run-time index here: a diagnostic build whose traversal kernel used scratch memory faulted with
@@ -1008,7 +1013,7 @@ __device__ inline void traverse_shadow_pool(const SceneView& sc, const PathState
     T.start(stack, q);
     T.cur = TRAV_DONE;
 #if FOVPT_V_CYCLES
-    C.last = cyc_stamp(T.cur);
+    if (C.on && cyc_first_lane()) s_cyc_acc[15] = cyc_stamp();
 #endif
     RayT r = {};
     uint32_t ph = 0;                              // physical index of the quad's shadow record
@@ -1033,15 +1038,64 @@ __device__ inline void traverse_shadow_pool(const SceneView& sc, const PathState
             }
             next = min(end, next + n_idle);
 #if FOVPT_V_CYCLES
-            C.last = cyc_stamp(T.cur);
+            if (C.on && cyc_first_lane()) s_cyc_acc[15] = cyc_stamp();
 #endif
             if (n_idle == 16u && __builtin_amdgcn_ballot_w64(T.cur != TRAV_DONE) == 0ull) return;      // pool exhausted, all results stored
         }
+#if FOVPT_V_IFIF
+        // if-if form (see traverse_quad_ifif): every pass steps every quad that has a ray, node or leaf, behind one wait
+        // for memory; passes repeat until a quad finishes (then the refill rule above gets its turn)
+        const unsigned long long idle_now = __builtin_amdgcn_ballot_w64(T.cur == TRAV_DONE);
+        if (idle_now == ~0ull) continue;
+        do {
+            if (T.cur != TRAV_DONE) {
+                const char* base = (const char*)sc.nodes;
+                const bool leaf = T.cur < 0;
+                uint32_t off = ((uint32_t)T.cur << 7) | q.j32;
+                float4 c;
+                if (leaf) {
+                    const uint32_t lcode = (uint32_t)~T.cur;
+                    const uint32_t tri16 = (lcode >> 3) + (q.j <= (lcode & 7u) ? q.j3 : 0u);
+                    off = sc.tri_off + (tri16 << 4);
+                    c = *(const float4*)(base + off + 32);
+                }
+                const float4 a = *(const float4*)(base + off), b = *(const float4*)(base + off + 16);
+                if (!leaf) {
+                    const int code = __float_as_int(b.z);
+                    float t;
+                    const bool h = box_hit(r, a.x, a.y, a.z, a.w, b.x, b.y, TMIN, TMAX, t);
+                    const uint32_t m4 = (uint32_t)(__builtin_amdgcn_ballot_w64(h) >> q.qshift) & 15u;
+                    int Hm1;
+                    asm("v_bcnt_u32_b32 %0, %1, -1" : "=v"(Hm1) : "v"(m4), "v"(b.w));
+                    const int row = ((__builtin_popcount(m4 & q.from_me) - 1) << 8) + (h ? 0 : q.miss_rows);
+                    *(int*)(T.top + row) = code;
+                    T.top += Hm1 * ROWB;
+                    __builtin_amdgcn_wave_barrier();
+                    T.cur = *(const int*)T.top;
+                } else {
+                    const V3 d = v3(r.dx, r.dy, r.dz);
+                    const V3 e1 = v3(a.w, b.x, b.y), e2 = v3(b.z, b.w, c.x);
+                    const V3 p = cross(d, e2);
+                    const float det = dot(e1, p);
+                    const float inv = 1.0f / det;
+                    const V3 sv = v3(r.ox, r.oy, r.oz) - v3(a.x, a.y, a.z);
+                    const float u = dot(sv, p) * inv;
+                    const V3 qq = cross(sv, e1);
+                    const float v = dot(d, qq) * inv;
+                    const float t = dot(e2, qq) * inv;
+                    const bool ok = (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > TMIN) & (t < TMAX);
+                    if ((uint32_t)(__builtin_amdgcn_ballot_w64(ok & (det > 0.0f)) >> q.qshift) & 15u) { occluded = true; T.cur = TRAV_DONE; }
+                    else { T.top -= ROWB; T.cur = *(const int*)T.top; }
+                }
+            }
+        } while (__builtin_amdgcn_ballot_w64(T.cur == TRAV_DONE) == idle_now);
+#else
         while (T.cur >= 0) { STEPSTAT(diag); node_step<true>(sc, r, q, T CYC_A); }
         if (T.cur != TRAV_DONE) {
             STEPSTAT(diag + 2);
             if (leaf_step<true>(sc, r, q, T CYC_A)) { occluded = true; T.cur = TRAV_DONE; }
         }
+#endif
     }
 }
 
@@ -1066,19 +1120,15 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
     }
     QuadLane q;
     q.init();
-#if FOVPT_V_CYCLES
-    uint32_t stack_byte = threadIdx.x & ~3u;          // opaque copies: the flush at the end rebuilds the thread index from
-    asm volatile("" : "+v"(stack_byte), "+v"(q.j), "+v"(q.qshift));     // values that are live anyway (no spill, no scratch)
-    int* stack = (int*)((char*)s_stack + stack_byte);
-#else
     int* stack = s_stack + (threadIdx.x >> 2);
-#endif
 #if FOVPT_V_CYCLES
     if (threadIdx.x < 192) s_cyc_hist[threadIdx.x] = 0u;
+    if (threadIdx.x < 16) s_cyc_acc[threadIdx.x] = 0u;
     __syncthreads();
-    Cyc C; C.init();
+    Cyc C;
+    C.on = __builtin_amdgcn_readfirstlane((blockIdx.x < 256u && threadIdx.x < 64u) ? 1 : 0) != 0;
+    const unsigned long long real0 = __builtin_amdgcn_s_memrealtime();      // every wave: when it starts and ends (100 MHz)
     const uint32_t life0 = cyc_stamp();
-    const unsigned long long real0 = __builtin_amdgcn_s_memrealtime();
 #endif
     // occlusion rays: every wave owns one contiguous pool
     if (n_sh) {
@@ -1112,19 +1162,18 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
     {
         const uint32_t life1 = cyc_stamp();
         const unsigned long long real1 = __builtin_amdgcn_s_memrealtime();
-        const int kind = it_shadow >= 0 ? 1 : 0, itn = (it_shadow >= 0 ? it_shadow : it_closest) & 7;
-        unsigned long long* g = cnt->cyc[kind][itn];
-        if ((q.qshift | q.j) == 0u) {
+        const int kind = it_shadow >= 0 ? 1 : 0, itn = (it_shadow >= 0 ? it_shadow : it_closest) & 3;
+        const uint32_t wave = blockIdx.x * (FOVPT_BLOCK / 64) + (threadIdx.x >> 6);
+        if ((threadIdx.x & 63u) == 0u && wave < 8192u) { cnt->wtime[kind * 4 + itn][wave][0] = real0; cnt->wtime[kind * 4 + itn][wave][1] = real1; }
+        if (C.on && (threadIdx.x & 63u) == 0u) {
             const uint32_t x = cyc_stamp(), y = cyc_stamp();      // two stamps back to back: what a stamp costs
-            const uint32_t v[14] = {C.n_node, C.gap, C.load, C.alu, C.lds, C.n_leaf, C.lgap, C.lload, C.lrest, y - x, 1u,
-                                    life1 - life0, (uint32_t)(real1 - real0), 1u};
-#pragma unroll
-            for (int k = 0; k < 14; k++) atomicAdd(g + k, (unsigned long long)v[k]);
+            unsigned long long* g = cnt->cyc[kind][itn];
+            for (int k = 0; k < 9; k++) atomicAdd(g + k, (unsigned long long)s_cyc_acc[k]);
+            atomicAdd(g + 9, (unsigned long long)(y - x)); atomicAdd(g + 10, 1ull);
+            atomicAdd(g + 11, (unsigned long long)(life1 - life0)); atomicAdd(g + 12, (unsigned long long)(real1 - real0)); atomicAdd(g + 13, 1ull);
         }
-        __syncthreads();
-        // (the thread index rebuilt from values that are live through the loops: the build stays free of scratch)
-        const uint32_t tid = stack_byte | q.j;
-        if (tid < 192 && s_cyc_hist[tid]) atomicAdd(&cnt->hist[kind][itn][tid >> 6][tid & 63u], s_cyc_hist[tid]);
+        if (FOVPT_V_CYCLES >= 2 && C.on && threadIdx.x < 64u)
+            for (uint32_t k = threadIdx.x; k < 192u; k += 64u) if (s_cyc_hist[k]) atomicAdd(&cnt->hist[kind][itn][k >> 6][k & 63u], s_cyc_hist[k]);
     }
 #endif
 }

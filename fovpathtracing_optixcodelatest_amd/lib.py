@@ -18,6 +18,7 @@ EXPORTS = [
     "fovpt_synchronize", "fovpt_download", "fovpt_get_stats", "fovpt_reset_stats", "fovpt_stream",
     "fovpt_probe_build_cdf", "fovpt_camera_uvw", "fovpt_debug_math", "fovpt_debug_buffer",
     "fovpt_gather_plan", "fovpt_gather_pack", "fovpt_gather_unpack",
+    "fovpt_comm_get_unique_id", "fovpt_comm_init", "fovpt_comm_destroy", "fovpt_gather_frame",
     "fovpt_model_load_obj", "fovpt_model_destroy", "fovpt_model_counts", "fovpt_model_get_mesh", "fovpt_model_get_texture",
     "fovpt_image_load_float4", "fovpt_image_free",
 ]
@@ -102,6 +103,10 @@ def load():
     L.fovpt_gather_plan.argtypes = [vp, C.POINTER(abi.LaunchParams), vp, i32]
     L.fovpt_gather_pack.argtypes = [vp, vp, vp]
     L.fovpt_gather_unpack.argtypes = [vp, vp, u32, vp]
+    L.fovpt_comm_get_unique_id.argtypes = [vp]
+    L.fovpt_comm_init.argtypes = [vp, vp, i32, i32]
+    L.fovpt_comm_destroy.argtypes = [vp]
+    L.fovpt_gather_frame.argtypes = [vp, C.POINTER(abi.LaunchParams), i32, vp, vp]
     L.fovpt_debug_math.argtypes = [vp, i32, vp, vp, vp, sz]
     L.fovpt_debug_buffer.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(sz)]
     L.fovpt_model_load_obj.argtypes = [C.c_char_p, C.POINTER(vp)]

@@ -164,6 +164,22 @@ class SampleRenderer:
     def gather_unpack(self, gathered_ptr, stride, frame_ptr):
         self._check(self._L.fovpt_gather_unpack(self._ctx, gathered_ptr, stride, frame_ptr))
 
+    # -- the RCCL transport of that gather inside the library (fovpt_comm_*, fovpt_gather_frame): what a C++ host uses
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        lib.check(None, lib.load().fovpt_comm_get_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id, rank, world):
+        self._check(self._L.fovpt_comm_init(self._ctx, C.c_char_p(unique_id), rank, world))
+
+    def comm_destroy(self):
+        self._check(self._L.fovpt_comm_destroy(self._ctx))
+
+    def gather_frame(self, root, frame_ptr, full_frame_ptr):
+        self._check(self._L.fovpt_gather_frame(self._ctx, C.byref(self.launchParams), root, frame_ptr, full_frame_ptr))
+
     def launch(self, width, height):
         """One optixLaunch with the current launchParams (SimplePathtracer.cpp:148-157)."""
         self._check(self._L.fovpt_launch(self._ctx, C.byref(self.launchParams), width, height))

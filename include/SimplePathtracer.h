@@ -99,6 +99,16 @@ public:
         check(fovpt_set_probe(ctx, probe.width, probe.height, (const fovpt_float4*)probe.data, probe.pdfValuesX, probe.cdfValuesX,
                               probe.pdfValuesY, probe.cdfValuesY, (const fovpt_float3*)&probe.offset, &launchParams.probe));
     }
+    // ---- multi-GPU (new with this library; the reference is single-GPU): one SampleRenderer per GPU / process, rank and
+    // world in fovpt_config, the framebuffer gathered over RCCL on the library's stream (include/fovpt.h, fovpt_comm_*)
+    void renderAsync() { check(fovpt_render(ctx, reinterpret_cast<fovpt_launch_params*>(&launchParams))); }   // render() without the sync
+    void commInit(const void* uniqueId, int rank, int world) { check(fovpt_comm_init(ctx, uniqueId, rank, world)); }
+    // gathers the frame just rendered (the renderer's current frame_buffer) onto `root`; fullFrame: device memory, root only
+    void gatherFrame(int root, uint32_t* fullFrame)
+    {
+        check(fovpt_gather_frame(ctx, reinterpret_cast<const fovpt_launch_params*>(&launchParams), root,
+                                 (const uint32_t*)launchParams.frame.frame_buffer, fullFrame));
+    }
     // the reference's compile-time switches (FOV_ON/OFF, radii, spp, depth) as run-time settings
     fovpt_config config() const { fovpt_config c; fovpt_get_config(ctx, &c); return c; }
     void setConfig(const fovpt_config& c) { check(fovpt_set_config(ctx, &c)); }

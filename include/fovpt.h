@@ -272,6 +272,26 @@ int fovpt_gather_plan(fovpt_ctx* ctx, const fovpt_launch_params* lp, uint32_t* c
 int fovpt_gather_pack(fovpt_ctx* ctx, const uint32_t* frame, uint32_t* packed);
 int fovpt_gather_unpack(fovpt_ctx* ctx, const uint32_t* gathered, uint32_t stride, uint32_t* frame);
 
+/* ---- multi-GPU: the RCCL transport of that gather, for C / C++ hosts ----------------------
+ * One fovpt_ctx per GPU (one process or thread each), fovpt_config.rank / world set on each.
+ *   fovpt_comm_get_unique_id  ncclGetUniqueId: one rank creates the 128-byte id and hands it to the others out of band
+ *                             (MPI_Bcast, a file, a socket: the host application's business)
+ *   fovpt_comm_init           ncclCommInitRank on the context's device; collective over all ranks
+ *   fovpt_gather_frame        plan (cached) -> pack -> ncclGroupStart / ncclSend to `root` / on the root ncclRecv from every
+ *                             rank / ncclGroupEnd -> on the root unpack into full_frame.  Everything is enqueued on
+ *                             fovpt_stream(): asynchronous, ordered behind the frame just rendered, and running beside the
+ *                             next frame's rendering.  `frame` is this rank's rgba8 frame (what fovpt_render wrote);
+ *                             full_frame (root only; may be `frame` itself) receives the whole image.
+ *   fovpt_comm_destroy        ncclCommDestroy (also done by fovpt_destroy)
+ * librccl is loaded at run time (dlopen: $FOVPT_RCCL_LIB, librccl.so.1, librccl.so); without it these return
+ * FOVPT_E_DEVICE and everything else in this header works.  Replaces nothing in the reference (single-GPU,
+ * SimplePathtracer.cpp:331-340); the partition is the scheme of sutil/WorkDistribution.h:47-84.                        */
+#define FOVPT_COMM_ID_BYTES 128
+int fovpt_comm_get_unique_id(void* id);
+int fovpt_comm_init(fovpt_ctx* ctx, const void* id, int rank, int world);
+int fovpt_comm_destroy(fovpt_ctx* ctx);
+int fovpt_gather_frame(fovpt_ctx* ctx, const fovpt_launch_params* lp, int root, const uint32_t* frame, uint32_t* full_frame);
+
 /* CUDA_SYNC_CHECK() (SimplePathtracer.cpp:212). */
 int fovpt_synchronize(fovpt_ctx* ctx);
 

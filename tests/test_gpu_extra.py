@@ -225,6 +225,23 @@ def test_cpp_dropin_shim_end_to_end(oracle, tmp_path):
     assert np.array_equal(px, F.frame)
 
 
+def test_cpp_host_gathers_over_rccl(tmp_path):
+    """the multi-GPU transport reachable from the C++ host.  A C++ program drives SampleRenderer and the
+    library's own RCCL gather (fovpt_comm_init / fovpt_gather_frame: pack -> ncclSend / ncclRecv on fovpt_stream() -> unpack)
+    with a communicator of one rank, three frames back to back without host synchronisation: the gathered frame is the
+    rendered frame."""
+    exe, out = str(tmp_path / "rccl_gather_test"), str(tmp_path / "rccl_out.bin")
+    csrc = os.path.join(ROOT, "fovpathtracing_optixcodelatest_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "rccl_gather_test.cpp"), "-o", exe,
+                           "-L", csrc, "-lfovpt", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + csrc, "-Wl,-rpath,/opt/rocm/lib"])
+    res = subprocess.run([exe, out], capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stdout + res.stderr
+    px = np.fromfile(out, np.uint32).reshape(2, 96, 160)
+    assert (px[0] != 0).sum() > 0.9 * px[0].size
+    assert np.array_equal(px[0], px[1]), res.stdout
+
+
 def _write_textured_obj(tmp_path):
     rng = np.random.default_rng(4)
     tex = rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)

@@ -15,10 +15,12 @@ SETS[sq_wait]="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY 
 SETS[sq_cycles]="SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES"
 SETS[sq_level]="SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INST_LEVEL_LDS SQ_INSTS_LDS"
 SETS[tcp]="TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum GRBM_GUI_ACTIVE"
-SETS[ta]="TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE"
+# (four TA counters in one pass are over the TA block's slots: error code 38, measured in round 3 -- two per pass)
+SETS[ta]="TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum GRBM_GUI_ACTIVE"
+SETS[ta2]="TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE"
 SETS[tcc]="TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"
 NAMES="$@"
-[ -z "$NAMES" ] && NAMES="sq_insts sq_wait sq_cycles sq_level tcp ta tcc"
+[ -z "$NAMES" ] && NAMES="sq_insts sq_wait sq_cycles sq_level tcp ta ta2 tcc"
 for S in $NAMES; do
   OUT=$GRAFT_REPO_ROOT/gpurun_out/pmcset_${TAG}_$S
   mkdir -p $OUT
