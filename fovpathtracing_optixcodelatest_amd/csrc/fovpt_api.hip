@@ -1154,6 +1154,87 @@ int fovpt_debug_buffer(fovpt_ctx* c, const char* name, void** ptr, size_t* bytes
     return fail(c, FOVPT_E_INVALID, "unknown debug buffer %s", name);
 }
 
+// test hook: the PRODUCTION traversal kernel on a caller-supplied batch of rays -- closest hit (global primitive id, t, u, v)
+// and the occlusion predicate of the shadow rays (any front-facing candidate in (0.01, 1e16), deviceProgram.cu:224-248,
+// 284-300) -- so that optixTrace's two ray types can be compared with the oracle ray by ray, not only through frames.
+int fovpt_debug_trace(fovpt_ctx* c, int n, const float* origins3, const float* dirs3, uint32_t* prim_out, float* tuv_out3, uint8_t* occluded_out)
+{
+    if (!c || n < 0 || (n && (!origins3 || !dirs3))) return FOVPT_E_INVALID;
+    if (!c->has_scene) return fail(c, FOVPT_E_NO_SCENE, "fovpt_debug_trace without a scene");
+    if (n == 0) return FOVPT_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
+    StateSet& S = c->set[c->jobs & 1u];
+    const size_t slots = (size_t)n * FOVPT_SHARDS;                  // all rays go to shard 0: its capacity must hold them
+    int rc = ensure_state(c, S, slots, 1);
+    if (rc) return rc;
+    const uint32_t cap = shard_capacity(slots);
+    hipStream_t st = c->stream;
+    std::vector<float> o4((size_t)n * 4), d4((size_t)n * 4), d4s((size_t)n * 4), vis((size_t)n * 4, 0.f), occ((size_t)n * 4, 0.f);
+    for (int i = 0; i < n; i++) {
+        const uint32_t slot = (uint32_t)i, cell = 0u;
+        for (int k = 0; k < 3; k++) { o4[4 * (size_t)i + k] = origins3[3 * (size_t)i + k]; d4[4 * (size_t)i + k] = d4s[4 * (size_t)i + k] = dirs3[3 * (size_t)i + k]; }
+        memcpy(&o4[4 * (size_t)i + 3], &slot, 4);                   // origin.w = sample slot
+        d4[4 * (size_t)i + 3] = 0.f;
+        memcpy(&d4s[4 * (size_t)i + 3], &cell, 4);                  // shadow record: direction.w = target cell of the slot
+        vis[4 * (size_t)i] = 1.f; occ[4 * (size_t)i] = 2.f;         // what store_shadow leaves in the cell: 1 visible, 2 occluded
+    }
+    const size_t bytes = (size_t)n * 16;
+    HIPCHK(c, hipMemcpyAsync(S.q_o[0].p, o4.data(), bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(S.q_d[0].p, d4.data(), bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(S.sq_o[0].p, o4.data(), bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(S.sq_d[0].p, d4s.data(), bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(S.sq_vis[0].p, vis.data(), bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(S.sq_occ[0].p, occ.data(), bytes, hipMemcpyHostToDevice, st));
+    // queue sizes: n entries in shard 0 of the radiance queue of iteration 0 and of the shadow queue of iteration 0
+    HIPCHK(c, hipMemsetAsync(S.counters.p, 0, offsetof(Counters, stat_radiance), st));
+    const uint32_t un = (uint32_t)n;
+    Counters* cnt = (Counters*)S.counters.p;
+    HIPCHK(c, hipMemcpyAsync(&cnt->shard[0][FOVPT_CNT_Q(0)], &un, 4, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipMemcpyAsync(&cnt->shard[0][FOVPT_CNT_SQ(0)], &un, 4, hipMemcpyHostToDevice, st));
+    PathState ps;
+    memset(&ps, 0, sizeof(ps));
+    ps.thr = (float4*)S.s_thr.p; ps.rng = (uint4*)S.s_rng.p; ps.hit = (float4*)S.s_hit.p; ps.rad = (float4*)S.s_rad.p;
+    ps.stride = (size_t)c->cfg.max_depth; ps.alpha = (float4*)S.s_alpha.p; ps.backplate = (float4*)S.s_backplate.p;
+#if FOVPT_V_STEPSTAT
+    ps.trace = (uint4*)S.s_trace.p;
+#endif
+    RayQueue q; q.o = (float4*)S.q_o[0].p; q.d = (float4*)S.q_d[0].p;
+    ShadowQueue sq; sq.o = (float4*)S.sq_o[0].p; sq.d = (float4*)S.sq_d[0].p; sq.val_vis = (float4*)S.sq_vis[0].p; sq.val_occ = (float4*)S.sq_occ[0].p;
+    SceneView sc;
+    sc.nodes = c->nodes; sc.tris = c->tris; sc.tri_tc = (const float2*)c->tri_tc.p;
+    sc.meshes = (const MeshDev*)c->meshes.p; sc.textures = (const TexDev*)c->textures.p;
+    sc.num_tris = c->num_tris; sc.any_catcher = c->any_catcher;
+    sc.tri_off = (uint32_t)((const char*)c->tris - (const char*)c->nodes);
+    fovpt_launch_traverse(st, sc, ps, q, sq, cap, cnt, 0, -1, c->grid);              // closest hit, as run_job launches it
+    fovpt_launch_traverse(st, sc, ps, q, sq, cap, cnt, -1, 0, c->grid_shadow);       // occlusion, as run_job launches it
+    HIPCHK(c, hipGetLastError());
+    std::vector<float> hit((size_t)n * 4), cell((size_t)n * 4 * (size_t)c->cfg.max_depth);
+    HIPCHK(c, hipMemcpyAsync(hit.data(), S.s_hit.p, bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemcpyAsync(cell.data(), S.s_rad.p, bytes * (size_t)c->cfg.max_depth, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    std::vector<TriRec> tris(c->num_tris);                           // leaf order -> global primitive id
+    HIPCHK(c, hipMemcpy(tris.data(), c->tris, sizeof(TriRec) * (size_t)c->num_tris, hipMemcpyDeviceToHost));
+    // leave the set as a job expects to find it (resolve zeroes the queue counters at the end of every job)
+    HIPCHK(c, hipMemset(S.counters.p, 0, offsetof(Counters, stat_radiance)));
+    for (int i = 0; i < n; i++) {
+        uint32_t pos;
+        memcpy(&pos, &hit[4 * (size_t)i + 3], 4);
+        const bool miss = pos == 0xffffffffu;
+        const size_t tri = miss ? 0 : (size_t)pos / 3;               // pos: offset in 16-byte units, a record is 48 bytes
+        if (!miss && (pos % 3u != 0u || tri >= tris.size())) return fail(c, FOVPT_E_DEVICE, "hit record %d points at 16-byte unit %u", i, pos);
+        if (prim_out) prim_out[i] = miss ? 0xffffffffu : tris[tri].prim;
+        if (tuv_out3) for (int k = 0; k < 3; k++) tuv_out3[3 * (size_t)i + k] = hit[4 * (size_t)i + k];
+        if (occluded_out) {
+            const float v = cell[4 * (size_t)i * (size_t)c->cfg.max_depth];
+            if (v != 1.f && v != 2.f) return fail(c, FOVPT_E_DEVICE, "shadow ray %d left %g in its cell", i, (double)v);
+            occluded_out[i] = v == 2.f ? 1 : 0;
+        }
+    }
+    return FOVPT_OK;
+}
+
 int fovpt_debug_math(fovpt_ctx* c, int op, const float* a, const float* b, float* out, size_t n)
 {
     if (!c || !a || !out) return FOVPT_E_INVALID;

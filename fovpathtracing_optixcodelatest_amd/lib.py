@@ -16,7 +16,7 @@ EXPORTS = [
     "fovpt_create", "fovpt_destroy", "fovpt_last_error", "fovpt_set_scene", "fovpt_set_probe", "fovpt_set_probe_data",
     "fovpt_resize", "fovpt_get_config", "fovpt_set_config", "fovpt_launch", "fovpt_render",
     "fovpt_synchronize", "fovpt_download", "fovpt_get_stats", "fovpt_reset_stats", "fovpt_stream",
-    "fovpt_probe_build_cdf", "fovpt_camera_uvw", "fovpt_debug_math", "fovpt_debug_buffer",
+    "fovpt_probe_build_cdf", "fovpt_camera_uvw", "fovpt_debug_math", "fovpt_debug_buffer", "fovpt_debug_trace",
     "fovpt_gather_plan", "fovpt_gather_pack", "fovpt_gather_unpack",
     "fovpt_comm_get_unique_id", "fovpt_comm_init", "fovpt_comm_destroy", "fovpt_gather_frame",
     "fovpt_model_load_obj", "fovpt_model_destroy", "fovpt_model_counts", "fovpt_model_get_mesh", "fovpt_model_get_texture",
@@ -109,6 +109,7 @@ def load():
     L.fovpt_gather_frame.argtypes = [vp, C.POINTER(abi.LaunchParams), i32, vp, vp]
     L.fovpt_debug_math.argtypes = [vp, i32, vp, vp, vp, sz]
     L.fovpt_debug_buffer.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(sz)]
+    L.fovpt_debug_trace.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.fovpt_model_load_obj.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.fovpt_model_destroy.argtypes = [vp]
     L.fovpt_model_destroy.restype = None

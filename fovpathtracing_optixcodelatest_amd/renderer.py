@@ -266,6 +266,15 @@ class SampleRenderer:
         self.launchParams.probe = out
         return out
 
+    def debug_trace(self, origins, dirs):
+        """The production traversal kernel on a batch of rays -> (global prim id or 0xffffffff, (t, u, v), occluded 0 / 1)."""
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        prim, tuv, occ = np.empty(n, np.uint32), np.empty((n, 3), np.float32), np.empty(n, np.uint8)
+        self._check(self._L.fovpt_debug_trace(self._ctx, n, o.ctypes.data, d.ctypes.data, prim.ctypes.data, tuv.ctypes.data, occ.ctypes.data))
+        return prim, tuv, occ
+
     def debug_math(self, op, a, b=None):
         a = np.ascontiguousarray(a, np.float32)
         bb = np.ascontiguousarray(b, np.float32) if b is not None else None

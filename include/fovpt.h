@@ -359,6 +359,10 @@ void fovpt_image_free(fovpt_float4* texels);
 #define FOVPT_OP_RSQRTD 9   /* (float)(1.0 / (double)sqrtf(a)), maths.h:98 */
 #define FOVPT_OP_UNORM8 10  /* texel channel (uint8)a / 255.0f as the shading kernel computes it */
 int fovpt_debug_math(fovpt_ctx* ctx, int op, const float* a, const float* b, float* out, size_t n);
+/* tests only: the production traversal kernel on a batch of n rays (host arrays, 3 floats per origin / direction): closest
+ * hit -> global primitive id (0xffffffff = miss) and (t, u, v); occlusion ray (deviceProgram.cu:224-248) -> 0 / 1.
+ * Any output may be NULL.  Synchronises.                                                                              */
+int fovpt_debug_trace(fovpt_ctx* ctx, int n, const float* origins3, const float* dirs3, uint32_t* prim_out, float* tuv_out3, uint8_t* occluded_out);
 /* tests/diagnostics only: device address and size of an internal buffer ("sq_occ", "counters", "hit", "bvh_nodes", ...) */
 int fovpt_debug_buffer(fovpt_ctx* ctx, const char* name, void** ptr, size_t* bytes);
 

@@ -139,3 +139,60 @@ def test_device_math_against_the_reference_vectors():
     srgb = np.where(c < f32(0.0031308), f32(12.92) * c, f32(1.055) * powed - f32(0.055)).astype(f32)
     assert np.abs(srgb - z["out:color/to_srgb"].reshape(-1)).max() <= 4e-7
     r.close()
+
+
+def _rays_towards_the_scene(model, n, seed):
+    """Origins in and around the scene's bounds, directions towards random points of it (most rays hit something)."""
+    rng = np.random.default_rng(seed)
+    v = np.concatenate([m.vertex for m in model.meshes])
+    lo, hi = v.min(0), v.max(0)
+    ext = hi - lo
+    o = (lo - 0.3 * ext + rng.random((n, 3)) * 1.6 * ext).astype(np.float32)
+    target = (lo + rng.random((n, 3)) * ext).astype(np.float32)
+    d = target - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return o, d.astype(np.float32)
+
+
+@pytest.mark.parametrize("which", ["cornell", "atrium", "soup"])
+def test_rays_one_by_one_against_the_oracle_brute_force(oracle, which):
+    """a9 / a10 at ray level: the production traversal kernel on a batch of rays, closest hit AND the
+    occlusion predicate of the shadow rays (any candidate in (0.01, 1e16) on a front-facing triangle, no early-termination
+    dependence: deviceProgram.cu:224-248, 284-300), against the oracle's BRUTE-FORCE loop over all triangles -- primitive
+    id, t, u, v bit for bit, occlusion flag equal, for every ray."""
+    from fovpathtracing_optixcodelatest_amd import renderer
+    if which == "cornell":
+        model, n = scenes.cornell_box(), 20000
+    elif which == "atrium":
+        model, n = scenes.atrium(6000), 6000
+    else:
+        rng = np.random.default_rng(5)                       # a triangle soup with duplicated, coplanar and zero-area triangles
+        c = rng.uniform(-1, 1, (400, 1, 3)).astype(np.float32)
+        tri = (c + rng.normal(0, 0.25, (400, 3, 3))).astype(np.float32)
+        tri[:40] = tri[40:80]                                 # exact duplicates: ties broken by the lower primitive id
+        tri[80:100, 2] = tri[80:100, 1]                       # zero area
+        tri[100:140, :, 2] = 0.25                             # coplanar
+        model = scenes.Model([scenes.TriangleMesh(tri.reshape(-1, 3), np.arange(1200, dtype=np.uint32).reshape(-1, 3), scenes.matte((1, 1, 1)))])
+        n = 20000
+    o, d = _rays_towards_the_scene(model, n, 11)
+    # special cases: rays that start ON a surface (t ~ 0 is below tmin 0.01 and must be skipped), rays whose nearest candidate sits
+    # just below / above t = 0.01, and every ray once more reversed (the back-face case of the occlusion ray)
+    S = oracle.OracleScene(model)
+    p0, t0, _ = S.trace(o, d, brute=True)
+    hit = p0 != 0xFFFFFFFF
+    on = (o + d * t0[:, :1])[hit][:2000]                      # points on surfaces
+    dn = d[hit][:2000]
+    eps = np.float32([0.0, 0.005, 0.0099, 0.0101, 0.02])[np.arange(len(on)) % 5][:, None]
+    o2 = np.concatenate([o, on - dn * eps, o + d * (t0[:, :1] + 1.0) * hit[:, None]]).astype(np.float32)
+    d2 = np.concatenate([d, dn, -d]).astype(np.float32)
+    r = renderer.SampleRenderer(model)
+    gp, gt, gocc = r.debug_trace(o2, d2)
+    r.close()
+    wp, wt, wocc = S.trace(o2, d2, brute=True)
+    assert np.array_equal(gp, wp)
+    h = wp != 0xFFFFFFFF
+    assert np.array_equal(gt[h].view(np.uint32), wt[h].view(np.uint32))
+    assert np.array_equal(gocc, wocc)
+    assert h.sum() > len(o2) // 3 and 0.05 < wocc.mean() < 0.95       # both outcomes of both ray types are exercised
+    # back faces: among the reversed rays there are closest hits whose occlusion ray is NOT occluded only because of the facing
+    assert ((wp != 0xFFFFFFFF) & (wocc == 0)).sum() > 0
