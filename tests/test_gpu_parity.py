@@ -183,7 +183,7 @@ def test_rays_one_by_one_against_the_oracle_brute_force(oracle, which):
     on = (o + d * t0[:, :1])[hit][:2000]                      # points on surfaces
     dn = d[hit][:2000]
     eps = np.float32([0.0, 0.005, 0.0099, 0.0101, 0.02])[np.arange(len(on)) % 5][:, None]
-    o2 = np.concatenate([o, on - dn * eps, o + d * (t0[:, :1] + 1.0) * hit[:, None]]).astype(np.float32)
+    o2 = np.concatenate([o, on - dn * eps, o + d * np.where(hit, t0[:, 0] + 1.0, 0.0)[:, None]]).astype(np.float32)
     d2 = np.concatenate([d, dn, -d]).astype(np.float32)
     r = renderer.SampleRenderer(model)
     gp, gt, gocc = r.debug_trace(o2, d2)
