@@ -727,10 +727,15 @@ __device__ inline void stepstat(unsigned long long* diag)
 // blocks, about one wave per CU.  (Stamping every wave makes the launch 4-8 x slower: 8192 waves x 4 stamps per step is
 // more than the timestamp path serves, and the time lands in whatever segment a wave happens to wait in.)  A stamp is tied
 // to the registers whose arrival it marks (asm operands), so the compiler's own waits sit in front of it.  The sums are
-// WAVE-level: the first active lane of a step adds them to a per-block LDS record (a variable carried through the
-// divergent step loops would be per lane).  FOVPT_V_CYCLES=2 adds histograms.
-struct Cyc { bool on; };
-__shared__ uint32_t s_cyc_acc[16];                    // 0 n_node, 1 gap, 2 load, 3 alu, 4 lds, 5 n_leaf, 6 lgap, 7 lload, 8 lrest, 15 last stamp
+// WAVE-level: a variable carried through the divergent step loops is per lane, so only the FIRST ACTIVE LANE of a step adds
+// the step's times to its own registers (a select, no branch) and the lanes' sums are added up at the end; the stamp that
+// ends a step travels to the next one through one LDS word.  FOVPT_V_CYCLES=2 adds histograms.
+struct Cyc {
+    bool on;
+    uint32_t n_node, gap, load, alu, lds, n_leaf, lgap, lload, lrest;     // per LANE; only the first active lane of a step adds to its own
+    __device__ inline void init(bool sampled) { on = sampled; n_node = gap = load = alu = lds = n_leaf = lgap = lload = lrest = 0u; }
+};
+__shared__ uint32_t s_cyc_last;                       // stamp at the end of the sampled wave's previous step (every active lane writes the same value)
 __shared__ uint32_t s_cyc_hist[3 * 64];               // node load wait /16 | node step /32 | leaf step /32
 __device__ inline uint32_t cyc_stamp()
 { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : : "memory"); return (uint32_t)t; }
@@ -799,14 +804,11 @@ __device__ inline void node_step(const SceneView& sc, const RayT& r, const QuadL
 #if FOVPT_V_CYCLES
     if (C.on) {
         const uint32_t c3 = cyc_stamp(T.cur);
-        if (cyc_first_lane()) {
-            const uint32_t last = s_cyc_acc[15];
-            atomicAdd(&s_cyc_acc[0], 1u); atomicAdd(&s_cyc_acc[1], c0 - last); atomicAdd(&s_cyc_acc[2], c1 - c0);
-            atomicAdd(&s_cyc_acc[3], c2 - c1); atomicAdd(&s_cyc_acc[4], c3 - c2);
-            cyc_hist(s_cyc_hist, (c1 - c0) >> 4);
-            cyc_hist(s_cyc_hist + 64, (c3 - last) >> 5);
-            s_cyc_acc[15] = cyc_stamp();               // (the bookkeeping itself stays out of the next step's gap)
-        }
+        const uint32_t last = s_cyc_last;
+        const uint32_t f = cyc_first_lane() ? 0xffffffffu : 0u;
+        C.n_node += f & 1u; C.gap += f & (c0 - last); C.load += f & (c1 - c0); C.alu += f & (c2 - c1); C.lds += f & (c3 - c2);
+        if (FOVPT_V_CYCLES >= 2 && f) { cyc_hist(s_cyc_hist, (c1 - c0) >> 4); cyc_hist(s_cyc_hist + 64, (c3 - last) >> 5); }
+        s_cyc_last = cyc_stamp();                      // (the bookkeeping itself stays out of the next step's gap)
     }
 #endif
 }
@@ -826,9 +828,9 @@ __device__ inline bool leaf_step(const SceneView& sc, const RayT& r, const QuadL
 #if FOVPT_V_CYCLES
     TriRec R = load_tri_off(sc.tris, tri16 << 4);
     if (C.on) c1 = cyc_stamp(R.v0x, R.e2z);
-#define CYC_LEAF_END(x) if (C.on) { const uint32_t c2 = cyc_stamp(x); if (cyc_first_lane()) { const uint32_t last = s_cyc_acc[15]; \
-        atomicAdd(&s_cyc_acc[5], 1u); atomicAdd(&s_cyc_acc[6], c0 - last); atomicAdd(&s_cyc_acc[7], c1 - c0); atomicAdd(&s_cyc_acc[8], c2 - c1); \
-        cyc_hist(s_cyc_hist + 128, (c2 - last) >> 5); s_cyc_acc[15] = cyc_stamp(); } }
+#define CYC_LEAF_END(x) if (C.on) { const uint32_t c2 = cyc_stamp(x); const uint32_t last = s_cyc_last; const uint32_t f = cyc_first_lane() ? 0xffffffffu : 0u; \
+        C.n_leaf += f & 1u; C.lgap += f & (c0 - last); C.lload += f & (c1 - c0); C.lrest += f & (c2 - c1); \
+        if (FOVPT_V_CYCLES >= 2 && f) cyc_hist(s_cyc_hist + 128, (c2 - last) >> 5); s_cyc_last = cyc_stamp(); }
 #else
     const TriRec R = load_tri_off(sc.tris, tri16 << 4);
 #define CYC_LEAF_END(x)
@@ -902,7 +904,7 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
 {
     T.start(stack, q);
 #if FOVPT_V_CYCLES
-    if (C.on && cyc_first_lane()) s_cyc_acc[15] = cyc_stamp();
+    if (C.on) s_cyc_last = cyc_stamp();
 #endif
 #if FOVPT_V_STEPSTAT
     // (no arrays with a run-time index here: a diagnostic build whose traversal kernel used scratch memory faulted with
@@ -1013,7 +1015,7 @@ __device__ inline void traverse_shadow_pool(const SceneView& sc, const PathState
     T.start(stack, q);
     T.cur = TRAV_DONE;
 #if FOVPT_V_CYCLES
-    if (C.on && cyc_first_lane()) s_cyc_acc[15] = cyc_stamp();
+    if (C.on) s_cyc_last = cyc_stamp();
 #endif
     RayT r = {};
     uint32_t ph = 0;                              // physical index of the quad's shadow record
@@ -1038,7 +1040,7 @@ __device__ inline void traverse_shadow_pool(const SceneView& sc, const PathState
             }
             next = min(end, next + n_idle);
 #if FOVPT_V_CYCLES
-            if (C.on && cyc_first_lane()) s_cyc_acc[15] = cyc_stamp();
+            if (C.on) s_cyc_last = cyc_stamp();
 #endif
             if (n_idle == 16u && __builtin_amdgcn_ballot_w64(T.cur != TRAV_DONE) == 0ull) return;      // pool exhausted, all results stored
         }
@@ -1123,10 +1125,10 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
     int* stack = s_stack + (threadIdx.x >> 2);
 #if FOVPT_V_CYCLES
     if (threadIdx.x < 192) s_cyc_hist[threadIdx.x] = 0u;
-    if (threadIdx.x < 16) s_cyc_acc[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) s_cyc_last = 0u;
     __syncthreads();
     Cyc C;
-    C.on = __builtin_amdgcn_readfirstlane((blockIdx.x < 256u && threadIdx.x < 64u) ? 1 : 0) != 0;
+    C.init(FOVPT_V_CYCLES != 3 && __builtin_amdgcn_readfirstlane((blockIdx.x < 256u && threadIdx.x < 64u) ? 1 : 0) != 0);   // 3: wave start / end times only
     const unsigned long long real0 = __builtin_amdgcn_s_memrealtime();      // every wave: when it starts and ends (100 MHz)
     const uint32_t life0 = cyc_stamp();
 #endif
@@ -1165,12 +1167,16 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
         const int kind = it_shadow >= 0 ? 1 : 0, itn = (it_shadow >= 0 ? it_shadow : it_closest) & 3;
         const uint32_t wave = blockIdx.x * (FOVPT_BLOCK / 64) + (threadIdx.x >> 6);
         if ((threadIdx.x & 63u) == 0u && wave < 8192u) { cnt->wtime[kind * 4 + itn][wave][0] = real0; cnt->wtime[kind * 4 + itn][wave][1] = real1; }
-        if (C.on && (threadIdx.x & 63u) == 0u) {
-            const uint32_t x = cyc_stamp(), y = cyc_stamp();      // two stamps back to back: what a stamp costs
+        if (C.on) {
             unsigned long long* g = cnt->cyc[kind][itn];
-            for (int k = 0; k < 9; k++) atomicAdd(g + k, (unsigned long long)s_cyc_acc[k]);
-            atomicAdd(g + 9, (unsigned long long)(y - x)); atomicAdd(g + 10, 1ull);
-            atomicAdd(g + 11, (unsigned long long)(life1 - life0)); atomicAdd(g + 12, (unsigned long long)(real1 - real0)); atomicAdd(g + 13, 1ull);
+            const uint32_t v[9] = {C.n_node, C.gap, C.load, C.alu, C.lds, C.n_leaf, C.lgap, C.lload, C.lrest};
+#pragma unroll
+            for (int k = 0; k < 9; k++) if (v[k]) atomicAdd(g + k, (unsigned long long)v[k]);
+            if ((threadIdx.x & 63u) == 0u) {
+                const uint32_t x = cyc_stamp(), y = cyc_stamp();      // two stamps back to back: what a stamp costs
+                atomicAdd(g + 9, (unsigned long long)(y - x)); atomicAdd(g + 10, 1ull);
+                atomicAdd(g + 11, (unsigned long long)(life1 - life0)); atomicAdd(g + 12, (unsigned long long)(real1 - real0)); atomicAdd(g + 13, 1ull);
+            }
         }
         if (FOVPT_V_CYCLES >= 2 && C.on && threadIdx.x < 64u)
             for (uint32_t k = threadIdx.x; k < 192u; k += 64u) if (s_cyc_hist[k]) atomicAdd(&cnt->hist[kind][itn][k >> 6][k & 63u], s_cyc_hist[k]);

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from fovpathtracing_optixcodelatest_amd import abi, renderer, scenes, lib
 
-W, H = 1920, 1080
+W, H = (int(x) for x in os.environ.get("FOVPT_SIZE", "1920,1080").split(","))
 which = sys.argv[1] if len(sys.argv) > 1 else "atrium"
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 street = which == "street"
@@ -24,7 +24,7 @@ r = renderer.SampleRenderer(model); r.resize((W, H))
 cam = scenes.STREET_CAMERA if street else scenes.ATRIUM_CAMERA
 r.setCamera(renderer.Camera(cam["eye"], cam["lookat"], cam["up"], cam["fovy"], W / H))
 r.setProbe(renderer.ProbeData(scenes.sky_probe(512, 256, seed=5) if street else scenes.ambient_probe(W, H, 2.5)).BuildCDF())
-cfg = abi.Config.reference_default(); cfg.r_inner, cfg.r_outer = 148, 482
+cfg = abi.Config.reference_default(); cfg.r_inner, cfg.r_outer = 148 * H // 1080, 482 * H // 1080
 cfg.spp_periphery, cfg.spp_middle, cfg.spp_fovea = 1, 2, 8
 cfg.max_depth = int(os.environ.get("FOVPT_DEPTH", "4"))
 cfg.profile = int(os.environ.get("FOVPT_PROFILE", "2"))        # 2: every kernel alone (no overlap between the two streams)
@@ -66,13 +66,18 @@ for k in range(2):
         v = [float(x) for x in cyc[k, it]]
         n_node, gap, load, alu, lds, n_leaf, lgap, lload, lrest, cal, ncal, life, real, waves = v[:14]
         if waves == 0 or n_node == 0:
-            continue
+            if wt and (wt[-1][k * 4 + it][:, 1] > 0).any():
+                print("%-7s it %d |" % (names[k], it))
+                node = leaf = 0
+            else:
+                continue
         clock = life / (real / 100e6) / 1e9 if real else float("nan")        # s_memrealtime ticks at 100 MHz
-        node = gap + load + alu + lds
-        leaf = lgap + lload + lrest
-        print("%-7s it %d | sampled waves %4d  clock %.2f GHz  wave life %7.0f cyc (%.1f us)  in steps %4.1f %%  stamp %3.0f cyc"
+        if n_node:
+          node = gap + load + alu + lds
+          leaf = lgap + lload + lrest
+          print("%-7s it %d | sampled waves %4d  clock %.2f GHz  wave life %7.0f cyc (%.1f us)  in steps %4.1f %%  stamp %3.0f cyc"
               % (names[k], it, waves, clock, life / waves, life / waves / clock / 1e3, 100 * (node + leaf) / life, cal / max(ncal, 1)))
-        print("          node steps/wave %6.1f  cyc/step %6.0f = gap %4.0f + load %4.0f + alu %4.0f + lds %4.0f   (%.0f / %.0f / %.0f / %.0f %%)"
+          print("          node steps/wave %6.1f  cyc/step %6.0f = gap %4.0f + load %4.0f + alu %4.0f + lds %4.0f   (%.0f / %.0f / %.0f / %.0f %%)"
               % (n_node / waves, node / n_node, gap / n_node, load / n_node, alu / n_node, lds / n_node,
                  100 * gap / node, 100 * load / node, 100 * alu / node, 100 * lds / node))
         if n_leaf:
