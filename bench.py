@@ -29,6 +29,7 @@ import math
 import os
 import re
 import shutil
+import signal
 import subprocess
 import sys
 import tempfile
@@ -92,16 +93,33 @@ def run_counter_passes(timeout_s=90):
         d = tempfile.mkdtemp(prefix="fovpt_pmc_%s_" % tag, dir=os.environ.get("TMPDIR", "/tmp"))
         cmd = [exe, "--pmc"] + counters + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--",
                                            sys.executable, os.path.abspath(__file__), "--child-frames", "3"]
+        # The pass runs in a process group of its own: on a timeout the WHOLE group is killed -- rocprofv3 and the profiled
+        # python child -- so that nothing of it still holds the GPU when the timed region starts.
         try:
-            res = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=timeout_s,
-                                 env=dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp")))
+            proc = subprocess.Popen(cmd, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True,
+                                    env=dict(os.environ, TMPDIR=os.environ.get("TMPDIR", "/tmp")))
         except Exception as e:                                  # the run goes on without counters and says so
             shutil.rmtree(d, ignore_errors=True)
             return None, "rocprofv3 pass '%s' failed: %s" % (tag, type(e).__name__)
-        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-        if res.returncode != 0 or not files:
+        try:
+            proc.communicate(timeout=timeout_s)
+        except subprocess.TimeoutExpired:
+            for sig in (signal.SIGTERM, signal.SIGKILL):
+                try:
+                    os.killpg(proc.pid, sig)                    # the exact group this function started, nothing else
+                except ProcessLookupError:
+                    break
+                try:
+                    proc.communicate(timeout=10)
+                    break
+                except subprocess.TimeoutExpired:
+                    continue
             shutil.rmtree(d, ignore_errors=True)
-            return None, "rocprofv3 pass '%s' gave no counters (rc %d)" % (tag, res.returncode)
+            return None, "rocprofv3 pass '%s' timed out after %d s (its process group was killed)" % (tag, timeout_s)
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if proc.returncode != 0 or not files:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, "rocprofv3 pass '%s' gave no counters (rc %d)" % (tag, proc.returncode)
         disp = {}
         for f in files:
             for row in csv.DictReader(open(f)):
@@ -414,6 +432,34 @@ def main():
             traffic_source = "IMPORTED from profiles/pmc_traffic.json (not measured in this run: %s)" % counters_note
         except Exception:
             traffic_source = "unavailable: %s" % counters_note
+    # Latency model of the dominant kernel: what a launch should take if a wave's life is its chain of
+    # steps -- steps per wave x measured cycles per step (s_memtime stamps in a sample of the waves of a diagnostic build,
+    # profiles/r03_step_cycles.txt) -- and the launch lasts (wave life) / (wave slots busy over the launch) (every wave's
+    # start and end, profiles/r03_wave_timeline_c3.txt).  The step anatomy is IMPORTED from those committed profiles
+    # (tools/step_model.py); the launch times beside it are measured in this run.
+    latency_model = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_step_model.json")) as f:
+            sm = json.load(f)["launches"]
+        c1 = sm["closest_1"]
+        model_closest = sum(sm[k]["model"]["launch_us"] for k in sm if k.startswith("closest") and "model" in sm[k]) / 1e3
+        model_anyhit = sum(sm[k]["model"]["launch_us"] for k in sm if k.startswith("any-hit") and "model" in sm[k]) / 1e3
+        latency_model = {
+            "node_step_cycles": c1["node_step_cycles"], "leaf_step_cycles": c1["leaf_step_cycles"],
+            "load_wait_share_of_node_step": c1["model"]["load_wait_share_of_node_step"],
+            "node_steps_per_wave_per_launch": {k: sm[k]["node_steps_per_wave"] for k in sorted(sm) if "node_steps_per_wave" in sm[k]},
+            "wave_slots_busy_over_a_launch": {k: sm[k]["unstamped"]["wave_slots_busy"] for k in sorted(sm) if "unstamped" in sm[k]},
+            "model_ms_per_frame": {"traverse_closest": round(model_closest, 4), "traverse_occlusion": round(model_anyhit, 4)},
+            "measured_ms_per_frame_serialised": {"traverse_closest": ser["traverse_closest"], "traverse_occlusion": ser["traverse_occlusion"]},
+            "reading": "a node step of a wave (16 rays in lockstep) is ~1000 cycles, ~62 % of it the wait for the two 16-byte node loads of "
+                       "its slowest quad, 16 % box test + rank, 8 % LDS push / pop, 14 % loop; a launch lasts 1.35-2.5 x its average "
+                       "wave's life because every wave gets the same number of 16-ray rounds and the slowest of 8192 ends 25-55 % after "
+                       "the mean (wave slots busy 40-74 %)",
+            "source": "IMPORTED from profiles/r03_step_model.json (step anatomy, steps per wave, busy share: diagnostic builds); "
+                      "measured_ms_per_frame_serialised from this run",
+        }
+    except Exception as e:                                      # the line is still valid without the model
+        latency_model = {"unavailable": "%s: %s" % (type(e).__name__, e)}
     roofline = {
         "bound": "latency",
         "bound_note": "neither roof binds k_traverse: HBM traffic is a sixth of the algorithmic bytes (the scene stays in L2 / Infinity "
@@ -430,6 +476,7 @@ def main():
         "rays_per_launch": n_rays / max(1, n_launch), "algorithmic_bytes_per_ray": round(b_ray, 1),
         "per_frame_ms": per_frame_ms["overlapped"], "per_frame_ms_serialised": per_frame_ms["serialised"],
         "valu": valu,
+        "latency_model": latency_model,
     }
 
     out = {

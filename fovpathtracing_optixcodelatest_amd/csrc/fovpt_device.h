@@ -20,6 +20,10 @@
 #endif
 #define FOVPT_STACK 64            // traversal stack entries per ray, all in LDS (a wide node leaves <= 3 behind)
 #define FOVPT_QUADS_PER_BLOCK (FOVPT_BLOCK / 4)
+#ifndef FOVPT_TBLOCK
+#define FOVPT_TBLOCK 256          // threads per block of k_traverse (256 or 1024: the rays of a block share one LDS stack array)
+#endif
+#define FOVPT_TQUADS (FOVPT_TBLOCK / 4)
 #define FOVPT_MAX_PASSES 3
 #define FOVPT_MAX_ITERS 63         // wavefront iterations per frame (max_depth + catcher pass-throughs)
 #define FOVPT_SHARDS 8            // queue shards: one append counter per blockIdx % 8 (~ per XCD)

@@ -675,9 +675,10 @@ __device__ inline uint32_t quad_rot1(uint32_t v) { return (uint32_t)__builtin_am
 __device__ inline uint32_t quad_rot2(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true); }   // [2,3,0,1]
 __device__ inline uint32_t quad_rot3(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x93, 0xf, 0xf, true); }   // [3,0,1,2]
 
-enum { ROWB = FOVPT_QUADS_PER_BLOCK * 4 };      // byte distance of two stack rows
+enum { ROWB = FOVPT_TQUADS * 4,                 // byte distance of two stack rows
+       ROWSHIFT = FOVPT_TQUADS == 64 ? 8 : 10 };
 static_assert(FOVPT_LEAF_MAX <= 4, "a leaf is tested in one quad step");
-static_assert(FOVPT_QUADS_PER_BLOCK == 64, "row stride of the stack is 256 bytes");
+static_assert(FOVPT_TQUADS == 64 || FOVPT_TQUADS == 256, "row stride of the stack is 256 or 1024 bytes");
 
 struct QuadLane {                                   // per-lane constants of the quad traversal
     uint32_t j, qshift, from_me, j32, j3;
@@ -783,7 +784,7 @@ __device__ inline void node_step(const SceneView& sc, const RayT& r, const QuadL
     int row;                                    // in bytes, relative to top
     if (ANY_HIT) {
         // storage order (distance order was measured slower)
-        row = ((__builtin_popcount(m4 & q.from_me) - 1) << 8) + (h ? 0 : q.miss_rows);
+        row = ((__builtin_popcount(m4 & q.from_me) - 1) << ROWSHIFT) + (h ? 0 : q.miss_rows);
     } else {
         // front to back.  The key orders by entry distance (t >= TMIN > 0: the bit pattern is
         // monotonic) with the lane in the two lowest bits, so keys are distinct and below 2^31
@@ -792,7 +793,7 @@ __device__ inline void node_step(const SceneView& sc, const RayT& r, const QuadL
         uint32_t key;
         asm("v_and_or_b32 %0, %1, -4, %2" : "=v"(key) : "v"(h ? __float_as_uint(t) : 0u), "v"(q.j));
         const int lt = ((int)(quad_rot1(key) - key) >> 31) + ((int)(quad_rot2(key) - key) >> 31) + ((int)(quad_rot3(key) - key) >> 31);
-        row = (lt << 8) + 3 * ROWB;             // 3 - (number of keys below mine)
+        row = (lt << ROWSHIFT) + 3 * ROWB;             // 3 - (number of keys below mine)
     }
 #if FOVPT_V_CYCLES
     if (C.on) c2 = cyc_stamp(row, Hm1);
@@ -933,6 +934,9 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
 #ifndef FOVPT_V_IFIF
 #define FOVPT_V_IFIF 0
 #endif
+#ifndef FOVPT_V_DYN
+#define FOVPT_V_DYN 0              // 1: the waves of a block draw the block's closest-hit rounds from an LDS counter (see k_traverse)
+#endif
 #if FOVPT_V_IFIF
 // "if-if" form of the closest-hit traversal: ONE loop whose every pass lets each quad do whatever its ray needs next -- a
 // node test or a leaf test -- behind ONE wait for memory (nodes and triangles are reached through one base register, so the
@@ -966,7 +970,7 @@ __device__ inline void traverse_quad_ifif(const SceneView& sc, const RayT& r, in
             uint32_t key;
             asm("v_and_or_b32 %0, %1, -4, %2" : "=v"(key) : "v"(h ? __float_as_uint(t) : 0u), "v"(q.j));
             const int lt = ((int)(quad_rot1(key) - key) >> 31) + ((int)(quad_rot2(key) - key) >> 31) + ((int)(quad_rot3(key) - key) >> 31);
-            const int row = (lt << 8) + 3 * ROWB;
+            const int row = (lt << ROWSHIFT) + 3 * ROWB;
             *(int*)(T.top + row) = code;
             T.top += Hm1 * ROWB;
             __builtin_amdgcn_wave_barrier();
@@ -1069,7 +1073,7 @@ __device__ inline void traverse_shadow_pool(const SceneView& sc, const PathState
                     const uint32_t m4 = (uint32_t)(__builtin_amdgcn_ballot_w64(h) >> q.qshift) & 15u;
                     int Hm1;
                     asm("v_bcnt_u32_b32 %0, %1, -1" : "=v"(Hm1) : "v"(m4), "v"(b.w));
-                    const int row = ((__builtin_popcount(m4 & q.from_me) - 1) << 8) + (h ? 0 : q.miss_rows);
+                    const int row = ((__builtin_popcount(m4 & q.from_me) - 1) << ROWSHIFT) + (h ? 0 : q.miss_rows);
                     *(int*)(T.top + row) = code;
                     T.top += Hm1 * ROWB;
                     __builtin_amdgcn_wave_barrier();
@@ -1106,10 +1110,10 @@ __device__ inline void traverse_shadow_pool(const SceneView& sc, const PathState
 // iteration it_closest, one ray per QUAD of lanes (16 rays per wave).
 // (Dynamic work fetching with a global counter and per-lane replacement was measured and rejected: with
 // so few rays per resident lane per launch a returning atomic per wave costs more than the imbalance.)
-__global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneView sc, PathState ps, RayQueue queue, ShadowQueue sq,
+__global__ __launch_bounds__(FOVPT_TBLOCK, FOVPT_V_WAVES) void k_traverse(SceneView sc, PathState ps, RayQueue queue, ShadowQueue sq,
                                                                          uint32_t cap, Counters* __restrict__ cnt, int it_closest, int it_shadow)
 {
-    __shared__ int s_stack[(FOVPT_STACK + 4) * FOVPT_QUADS_PER_BLOCK];  // + the end marker and three rows of slack above the top
+    __shared__ int s_stack[(FOVPT_STACK + 4) * FOVPT_TQUADS];  // + the end marker and three rows of slack above the top
     ShardMap ms, mq;
     ms.load(cnt, FOVPT_CNT_SQ(it_shadow >= 0 ? it_shadow : 0));
     mq.load(cnt, FOVPT_CNT_Q(it_closest >= 0 ? it_closest : 0));
@@ -1134,13 +1138,48 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
 #endif
     // occlusion rays: every wave owns one contiguous pool
     if (n_sh) {
-        const uint32_t nwaves = gridDim.x * (FOVPT_BLOCK / 64), wave = blockIdx.x * (FOVPT_BLOCK / 64) + (threadIdx.x >> 6);
+        const uint32_t nwaves = gridDim.x * (FOVPT_TBLOCK / 64), wave = blockIdx.x * (FOVPT_TBLOCK / 64) + (threadIdx.x >> 6);
         const uint32_t per = (n_sh + nwaves - 1u) / nwaves, first = min(n_sh, wave * per);
         traverse_shadow_pool(sc, ps, sq, ms, cap, first, min(n_sh, first + per), stack, q, cnt->diag[1] CYC_A);
     }
+#if FOVPT_V_DYN
+    // closest-hit rays in ROUNDS of 16 consecutive rays per wave, handed out at run time INSIDE the block: its waves draw the
+    // block's rounds from a counter in LDS.  A launch lasts as long as its slowest wave, and with every wave given the same
+    // number of rounds the slowest of 8192 finishes 25-55 % after the average one (profiles/r03_wave_timeline_c3.txt).  Global
+    // counters cannot do this: a returning atomic per round costs 3-4 x the whole launch (tools/experiments/
+    // r03_dyn_global_atomics.patch), so the sharing stops at the block -- which is why the block is 16 waves here.  The block's
+    // rounds: in every group of 16 * gridDim.x consecutive rounds the 16 that start at 16 * blockIdx.x.
+    if (it_closest >= 0) {
+        __shared__ uint32_t s_next;
+        if (threadIdx.x == 0) s_next = 0u;
+        __syncthreads();
+        const uint32_t R = (n_cl + 15u) >> 4, NW = FOVPT_TBLOCK / 64;
+        for (;;) {
+            uint32_t c = 0;
+            if ((threadIdx.x & 63u) == 0u) c = atomicAdd(&s_next, 1u);
+            c = __builtin_amdgcn_readfirstlane(c);
+            const uint32_t rd = ((c / NW) * gridDim.x + blockIdx.x) * NW + (c % NW);
+            if (rd >= R) break;
+            const uint32_t i0 = rd << 4, i = i0 + ((threadIdx.x & 63u) >> 2);
+            if (i < n_cl) {
+                RayT r;
+                QuadTrav T;
+                const uint32_t ph = mq.phys16(i, i0, cap);
+                const float4 o = queue.o[ph], d = queue.d[ph];
+                ray_setup(r, o, d);
+#if FOVPT_V_IFIF
+                traverse_quad_ifif(sc, r, stack, q, T);
+#else
+                traverse_quad(sc, r, stack, q, T, cnt->diag[0] CYC_A);
+#endif
+                store_hit(ps, ph, T);
+            }
+        }
+    }
+#else
     // closest-hit rays: static grid-stride over quads, 16 consecutive rays per wave and round
-    const uint32_t quads = gridDim.x * FOVPT_QUADS_PER_BLOCK;
-    for (uint32_t i = blockIdx.x * FOVPT_QUADS_PER_BLOCK + (threadIdx.x >> 2); i < n_cl; i += quads) {
+    const uint32_t quads = gridDim.x * FOVPT_TQUADS;
+    for (uint32_t i = blockIdx.x * FOVPT_TQUADS + (threadIdx.x >> 2); i < n_cl; i += quads) {
         const uint32_t i0 = __builtin_amdgcn_readfirstlane(i - ((threadIdx.x & 63u) >> 2));      // the wave's 16 rays: i0 .. i0+15
         RayT r;
         QuadTrav T;
@@ -1160,12 +1199,13 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_WAVES) void k_traverse(SceneVi
         }
 #endif
     }
+#endif
 #if FOVPT_V_CYCLES
     {
         const uint32_t life1 = cyc_stamp();
         const unsigned long long real1 = __builtin_amdgcn_s_memrealtime();
         const int kind = it_shadow >= 0 ? 1 : 0, itn = (it_shadow >= 0 ? it_shadow : it_closest) & 3;
-        const uint32_t wave = blockIdx.x * (FOVPT_BLOCK / 64) + (threadIdx.x >> 6);
+        const uint32_t wave = blockIdx.x * (FOVPT_TBLOCK / 64) + (threadIdx.x >> 6);
         if ((threadIdx.x & 63u) == 0u && wave < 8192u) { cnt->wtime[kind * 4 + itn][wave][0] = real0; cnt->wtime[kind * 4 + itn][wave][1] = real1; }
         if (C.on) {
             unsigned long long* g = cnt->cyc[kind][itn];
@@ -1832,8 +1872,10 @@ void fovpt_launch_traverse(hipStream_t st, SceneView sc, PathState ps, RayQueue 
                            Counters* cnt, int it_closest, int it_shadow, int grid, hipEvent_t done)
 {
     // `done` rides on the kernel's own completion signal (no separate marker packet in the queue)
-    if (done) hipExtLaunchKernelGGL(k_traverse, dim3(grid), dim3(FOVPT_BLOCK), 0, st, nullptr, done, 0, sc, ps, queue, sq, cap, cnt, it_closest, it_shadow);
-    else hipLaunchKernelGGL(k_traverse, dim3(grid), dim3(FOVPT_BLOCK), 0, st, sc, ps, queue, sq, cap, cnt, it_closest, it_shadow);
+    // (`grid` counts blocks of 256 threads, as for the other kernels; the traversal block may be larger)
+    const int blocks = grid * FOVPT_BLOCK / FOVPT_TBLOCK > 0 ? grid * FOVPT_BLOCK / FOVPT_TBLOCK : 1;
+    if (done) hipExtLaunchKernelGGL(k_traverse, dim3(blocks), dim3(FOVPT_TBLOCK), 0, st, nullptr, done, 0, sc, ps, queue, sq, cap, cnt, it_closest, it_shadow);
+    else hipLaunchKernelGGL(k_traverse, dim3(blocks), dim3(FOVPT_TBLOCK), 0, st, sc, ps, queue, sq, cap, cnt, it_closest, it_shadow);
 }
 void fovpt_launch_shade(hipStream_t st, const FrameDev& fd, SceneView sc, PathState ps, RayQueue queue_in, RayQueue queue_out,
                         ShadowQueue sq, uint32_t cap, Counters* cnt, int depth, int grid, hipEvent_t done)
