@@ -931,78 +931,6 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
 #endif
 }
 
-#ifndef FOVPT_V_IFIF
-#define FOVPT_V_IFIF 0
-#endif
-#ifndef FOVPT_V_DYN
-#define FOVPT_V_DYN 0              // 1: the waves of a block draw the block's closest-hit rounds from an LDS counter (see k_traverse)
-#endif
-#if FOVPT_V_IFIF
-// "if-if" form of the closest-hit traversal: ONE loop whose every pass lets each quad do whatever its ray needs next -- a
-// node test or a leaf test -- behind ONE wait for memory (nodes and triangles are reached through one base register, so the
-// pass issues one set of loads for all quads).  In the while-while form above a ray that has reached a leaf waits until the
-// last ray of the wave has left the node phase (measured: of 12.3 rays alive in an average node step only 6.5 step), and
-// every leaf phase is a memory round trip of its own.
-__device__ inline void traverse_quad_ifif(const SceneView& sc, const RayT& r, int* __restrict__ stack, const QuadLane& q, QuadTrav& T)
-{
-    T.start(stack, q);
-    const char* base = (const char*)sc.nodes;
-    while (T.cur != TRAV_DONE) {
-        const bool leaf = T.cur < 0;
-        uint32_t off = ((uint32_t)T.cur << 7) | q.j32;
-        uint32_t tri16 = 0u;
-        float4 c;
-        if (leaf) {
-            const uint32_t lcode = (uint32_t)~T.cur;
-            tri16 = (lcode >> 3) + (q.j <= (lcode & 7u) ? q.j3 : 0u);     // in 16-byte units
-            off = sc.tri_off + (tri16 << 4);
-            c = *(const float4*)(base + off + 32);
-        }
-        const float4 a = *(const float4*)(base + off), b = *(const float4*)(base + off + 16);
-        if (!leaf) {
-            // ---- node_step<false>
-            const int code = __float_as_int(b.z);
-            float t;
-            const bool h = box_hit(r, a.x, a.y, a.z, a.w, b.x, b.y, TMIN, T.lim, t);
-            const uint32_t m4 = (uint32_t)(__builtin_amdgcn_ballot_w64(h) >> q.qshift) & 15u;
-            int Hm1;                                    // (b.w rides along unused: both parts then read ONE full 16-byte load of b)
-            asm("v_bcnt_u32_b32 %0, %1, -1" : "=v"(Hm1) : "v"(m4), "v"(b.w));
-            uint32_t key;
-            asm("v_and_or_b32 %0, %1, -4, %2" : "=v"(key) : "v"(h ? __float_as_uint(t) : 0u), "v"(q.j));
-            const int lt = ((int)(quad_rot1(key) - key) >> 31) + ((int)(quad_rot2(key) - key) >> 31) + ((int)(quad_rot3(key) - key) >> 31);
-            const int row = (lt << ROWSHIFT) + 3 * ROWB;
-            *(int*)(T.top + row) = code;
-            T.top += Hm1 * ROWB;
-            __builtin_amdgcn_wave_barrier();
-            T.cur = *(const int*)T.top;
-        } else {
-            // ---- leaf_step<false>
-            const V3 d = v3(r.dx, r.dy, r.dz);
-            const V3 e1 = v3(a.w, b.x, b.y), e2 = v3(b.z, b.w, c.x);
-            const uint32_t prim = __float_as_uint(c.y);
-            const V3 p = cross(d, e2);
-            const float det = dot(e1, p);
-            const float inv = 1.0f / det;
-            const V3 sv = v3(r.ox, r.oy, r.oz) - v3(a.x, a.y, a.z);
-            const float u = dot(sv, p) * inv;
-            const V3 qq = cross(sv, e1);
-            const float v = dot(d, qq) * inv;
-            const float t = dot(e2, qq) * inv;
-            const bool ok = (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > TMIN) & (t < TMAX);
-            const bool better = ok & ((t < T.bt) | ((t == T.bt) & (prim < T.bprim)));
-            T.bt = better ? t : T.bt; T.bu = better ? u : T.bu; T.bv = better ? v : T.bv;
-            T.bpos = better ? tri16 : T.bpos; T.bprim = better ? prim : T.bprim;
-            uint32_t m = __float_as_uint(T.bt);
-            m = min(m, quad_rot2(m));
-            m = min(m, quad_rot1(m));
-            T.lim = fminf(TMAX, __uint_as_float(m) * 1.000001f);
-            T.top -= ROWB;
-            T.cur = *(const int*)T.top;
-        }
-    }
-}
-#endif
-
 // Any-hit traversal over a POOL of shadow rays [first, end) owned by one wave: a quad that has finished
 // its ray takes the next one of the pool as soon as FOVPT_REFILL quads of the wave are idle (all of them
 // at the end), so the wave does not wait for its longest ray after every 16 -- occlusion rays end after
@@ -1048,60 +976,11 @@ __device__ inline void traverse_shadow_pool(const SceneView& sc, const PathState
 #endif
             if (n_idle == 16u && __builtin_amdgcn_ballot_w64(T.cur != TRAV_DONE) == 0ull) return;      // pool exhausted, all results stored
         }
-#if FOVPT_V_IFIF
-        // if-if form (see traverse_quad_ifif): every pass steps every quad that has a ray, node or leaf, behind one wait
-        // for memory; passes repeat until a quad finishes (then the refill rule above gets its turn)
-        const unsigned long long idle_now = __builtin_amdgcn_ballot_w64(T.cur == TRAV_DONE);
-        if (idle_now == ~0ull) continue;
-        do {
-            if (T.cur != TRAV_DONE) {
-                const char* base = (const char*)sc.nodes;
-                const bool leaf = T.cur < 0;
-                uint32_t off = ((uint32_t)T.cur << 7) | q.j32;
-                float4 c;
-                if (leaf) {
-                    const uint32_t lcode = (uint32_t)~T.cur;
-                    const uint32_t tri16 = (lcode >> 3) + (q.j <= (lcode & 7u) ? q.j3 : 0u);
-                    off = sc.tri_off + (tri16 << 4);
-                    c = *(const float4*)(base + off + 32);
-                }
-                const float4 a = *(const float4*)(base + off), b = *(const float4*)(base + off + 16);
-                if (!leaf) {
-                    const int code = __float_as_int(b.z);
-                    float t;
-                    const bool h = box_hit(r, a.x, a.y, a.z, a.w, b.x, b.y, TMIN, TMAX, t);
-                    const uint32_t m4 = (uint32_t)(__builtin_amdgcn_ballot_w64(h) >> q.qshift) & 15u;
-                    int Hm1;
-                    asm("v_bcnt_u32_b32 %0, %1, -1" : "=v"(Hm1) : "v"(m4), "v"(b.w));
-                    const int row = ((__builtin_popcount(m4 & q.from_me) - 1) << ROWSHIFT) + (h ? 0 : q.miss_rows);
-                    *(int*)(T.top + row) = code;
-                    T.top += Hm1 * ROWB;
-                    __builtin_amdgcn_wave_barrier();
-                    T.cur = *(const int*)T.top;
-                } else {
-                    const V3 d = v3(r.dx, r.dy, r.dz);
-                    const V3 e1 = v3(a.w, b.x, b.y), e2 = v3(b.z, b.w, c.x);
-                    const V3 p = cross(d, e2);
-                    const float det = dot(e1, p);
-                    const float inv = 1.0f / det;
-                    const V3 sv = v3(r.ox, r.oy, r.oz) - v3(a.x, a.y, a.z);
-                    const float u = dot(sv, p) * inv;
-                    const V3 qq = cross(sv, e1);
-                    const float v = dot(d, qq) * inv;
-                    const float t = dot(e2, qq) * inv;
-                    const bool ok = (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > TMIN) & (t < TMAX);
-                    if ((uint32_t)(__builtin_amdgcn_ballot_w64(ok & (det > 0.0f)) >> q.qshift) & 15u) { occluded = true; T.cur = TRAV_DONE; }
-                    else { T.top -= ROWB; T.cur = *(const int*)T.top; }
-                }
-            }
-        } while (__builtin_amdgcn_ballot_w64(T.cur == TRAV_DONE) == idle_now);
-#else
         while (T.cur >= 0) { STEPSTAT(diag); node_step<true>(sc, r, q, T CYC_A); }
         if (T.cur != TRAV_DONE) {
             STEPSTAT(diag + 2);
             if (leaf_step<true>(sc, r, q, T CYC_A)) { occluded = true; T.cur = TRAV_DONE; }
         }
-#endif
     }
 }
 
@@ -1142,41 +1021,6 @@ __global__ __launch_bounds__(FOVPT_TBLOCK, FOVPT_V_WAVES) void k_traverse(SceneV
         const uint32_t per = (n_sh + nwaves - 1u) / nwaves, first = min(n_sh, wave * per);
         traverse_shadow_pool(sc, ps, sq, ms, cap, first, min(n_sh, first + per), stack, q, cnt->diag[1] CYC_A);
     }
-#if FOVPT_V_DYN
-    // closest-hit rays in ROUNDS of 16 consecutive rays per wave, handed out at run time INSIDE the block: its waves draw the
-    // block's rounds from a counter in LDS.  A launch lasts as long as its slowest wave, and with every wave given the same
-    // number of rounds the slowest of 8192 finishes 25-55 % after the average one (profiles/r03_wave_timeline_c3.txt).  Global
-    // counters cannot do this: a returning atomic per round costs 3-4 x the whole launch (tools/experiments/
-    // r03_dyn_global_atomics.patch), so the sharing stops at the block -- which is why the block is 16 waves here.  The block's
-    // rounds: in every group of 16 * gridDim.x consecutive rounds the 16 that start at 16 * blockIdx.x.
-    if (it_closest >= 0) {
-        __shared__ uint32_t s_next;
-        if (threadIdx.x == 0) s_next = 0u;
-        __syncthreads();
-        const uint32_t R = (n_cl + 15u) >> 4, NW = FOVPT_TBLOCK / 64;
-        for (;;) {
-            uint32_t c = 0;
-            if ((threadIdx.x & 63u) == 0u) c = atomicAdd(&s_next, 1u);
-            c = __builtin_amdgcn_readfirstlane(c);
-            const uint32_t rd = ((c / NW) * gridDim.x + blockIdx.x) * NW + (c % NW);
-            if (rd >= R) break;
-            const uint32_t i0 = rd << 4, i = i0 + ((threadIdx.x & 63u) >> 2);
-            if (i < n_cl) {
-                RayT r;
-                QuadTrav T;
-                const uint32_t ph = mq.phys16(i, i0, cap);
-                const float4 o = queue.o[ph], d = queue.d[ph];
-                ray_setup(r, o, d);
-#if FOVPT_V_IFIF
-                traverse_quad_ifif(sc, r, stack, q, T);
-#else
-                traverse_quad(sc, r, stack, q, T, cnt->diag[0] CYC_A);
-#endif
-                store_hit(ps, ph, T);
-            }
-        }
-    }
-#else
     // closest-hit rays: static grid-stride over quads, 16 consecutive rays per wave and round
     const uint32_t quads = gridDim.x * FOVPT_TQUADS;
     for (uint32_t i = blockIdx.x * FOVPT_TQUADS + (threadIdx.x >> 2); i < n_cl; i += quads) {
@@ -1186,11 +1030,7 @@ __global__ __launch_bounds__(FOVPT_TBLOCK, FOVPT_V_WAVES) void k_traverse(SceneV
         const uint32_t ph = mq.phys16(i, i0, cap);
         const float4 o = queue.o[ph], d = queue.d[ph];
         ray_setup(r, o, d);
-#if FOVPT_V_IFIF
-        traverse_quad_ifif(sc, r, stack, q, T);
-#else
         traverse_quad(sc, r, stack, q, T, cnt->diag[0] CYC_A);
-#endif
         store_hit(ps, ph, T);
 #if FOVPT_V_STEPSTAT
         if (q.j == 0) {                                                   // tools/raystat.py, raytrace_dump.py
@@ -1199,7 +1039,6 @@ __global__ __launch_bounds__(FOVPT_TBLOCK, FOVPT_V_WAVES) void k_traverse(SceneV
         }
 #endif
     }
-#endif
 #if FOVPT_V_CYCLES
     {
         const uint32_t life1 = cyc_stamp();

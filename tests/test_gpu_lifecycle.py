@@ -528,7 +528,7 @@ def test_stereo_asymmetric_frusta(oracle):
     r.close()
 
 
-_FUZZ_LC = range(int(os.environ.get("FOVPT_FUZZLC_FROM", "0")), int(os.environ.get("FOVPT_FUZZLC_TO", "6")))
+_FUZZ_LC = range(int(os.environ.get("FOVPT_FUZZLC_FROM", "0")), int(os.environ.get("FOVPT_FUZZLC_TO", "24")))
 
 
 @pytest.mark.parametrize("seed", _FUZZ_LC)
