@@ -493,11 +493,11 @@ __global__ void k_emit_tiny(int n, const Box* __restrict__ boxes, BvhNode4* __re
 }
 
 __global__ void k_emit_tris_generic(const float* __restrict__ flat, const uint32_t* __restrict__ mesh_of_prim, const uint32_t* __restrict__ vals,
-                                    const uint32_t* __restrict__ leaf_pos, uint32_t n, TriRec* __restrict__ tris)
+                                    const uint32_t* __restrict__ ref_prim, const uint32_t* __restrict__ leaf_pos, uint32_t n, TriRec* __restrict__ tris)
 {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t prim = vals[i];
+    const uint32_t prim = ref_prim ? ref_prim[vals[i]] : vals[i];   // a reference of a split triangle stands for the whole triangle
     const float* p = flat + (size_t)prim * 9;
     TriRec t;
     t.v0x = p[0]; t.v0y = p[1]; t.v0z = p[2];
@@ -507,13 +507,109 @@ __global__ void k_emit_tris_generic(const float* __restrict__ flat, const uint32
     tris[leaf_pos[i]] = t;
 }
 
+// ---- spatial splits before the sort (early split clipping) ---------------------------------------------------------------
+// A triangle whose box is long against the scene's typical geometry -- a diagonal card, a long sliver -- is entered into the
+// build as several REFERENCES: its box is cut into k slabs along its longest axis and each reference gets the bounds of the
+// triangle clipped to its slab (Ernst & Greiner 2007; the budget idea of Karras & Aila 2013).  The hierarchy is built over
+// references; every reference of a triangle becomes a leaf record of the WHOLE triangle with the triangle's global primitive
+// id, so a ray may test a triangle more than once and the result -- minimum (t, primitive id), any front-facing candidate --
+// is what it was (tests/test_gpu_parity.py).  k = clamp(floor(longest extent / s), 1, FOVPT_SPLIT_MAX); s is found by bisection
+// so that the references number (1 + budget) x the triangles.
+#define FOVPT_SPLIT_MAX 8
+__device__ inline uint32_t split_count(const float* __restrict__ p, float s)
+{
+    float ext = 0.f;
+    for (int a = 0; a < 3; a++) ext = fmaxf(ext, fmaxf(p[a], fmaxf(p[3 + a], p[6 + a])) - fminf(p[a], fminf(p[3 + a], p[6 + a])));
+    const float k = floorf(ext / s);
+    return k >= (float)FOVPT_SPLIT_MAX ? (uint32_t)FOVPT_SPLIT_MAX : k >= 1.f ? (uint32_t)k : 1u;
+}
+__global__ void k_split_count(const float* __restrict__ flat, uint32_t n, float s, uint32_t* __restrict__ count, unsigned long long* __restrict__ total)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t k = i < n ? split_count(flat + (size_t)i * 9, s) : 0u;
+    if (count && i < n) count[i] = k;
+    for (int off = 32; off > 0; off >>= 1) k += __shfl_xor(k, off);
+    if ((threadIdx.x & 63) == 0 && k) atomicAdd(total, (unsigned long long)k);
+}
+__global__ void k_scene_extent(const float* __restrict__ flat, uint32_t n, uint32_t* __restrict__ bounds)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int a = 0; a < 3; a++) {
+        float mn = INFINITY, mx = -INFINITY;
+        if (i < n) { const float* p = flat + (size_t)i * 9; mn = fminf(p[a], fminf(p[3 + a], p[6 + a])); mx = fmaxf(p[a], fmaxf(p[3 + a], p[6 + a])); }
+        for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&bounds[a], f2ord(mn)); atomicMax(&bounds[3 + a], f2ord(mx)); }
+    }
+}
+// references of triangle i: padded bounds of the triangle clipped to each slab; bounds[] collects the centroid bounds as k_tri_bounds does
+__global__ void k_split_emit(const float* __restrict__ flat, uint32_t n, const uint32_t* __restrict__ count, const uint32_t* __restrict__ first,
+                             Box* __restrict__ boxes, uint32_t* __restrict__ ref_prim, uint32_t* __restrict__ bounds)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    float cmn[3] = {INFINITY, INFINITY, INFINITY}, cmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    if (i < n) {
+        const float* p = flat + (size_t)i * 9;
+        float lo[3], hi[3], ext = 0.f, mag = 0.f;
+        int ax = 0;
+        for (int a = 0; a < 3; a++) {
+            lo[a] = fminf(p[a], fminf(p[3 + a], p[6 + a])); hi[a] = fmaxf(p[a], fmaxf(p[3 + a], p[6 + a]));
+            if (hi[a] - lo[a] > ext) { ext = hi[a] - lo[a]; ax = a; }
+            mag = fmaxf(mag, fmaxf(fabsf(lo[a]), fabsf(hi[a])));
+        }
+        const float pad = 1e-4f * ext + 1e-5f * mag + 1e-20f;      // as k_tri_bounds: of the WHOLE triangle (also covers the clipping's rounding)
+        const uint32_t k = count[i], f = first[i];
+        for (uint32_t j = 0; j < k; j++) {
+            Box b;
+            if (k == 1u) { for (int a = 0; a < 3; a++) { b.lo[a] = lo[a]; b.hi[a] = hi[a]; } }
+            else {
+                const float c0 = j == 0u ? lo[ax] : lo[ax] + (hi[ax] - lo[ax]) * ((float)j / (float)k);
+                const float c1 = j + 1u == k ? hi[ax] : lo[ax] + (hi[ax] - lo[ax]) * ((float)(j + 1u) / (float)k);
+                for (int a = 0; a < 3; a++) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
+                for (int e = 0; e < 3; e++) {                          // vertices inside the slab, and where the edges cross its two planes
+                    const float* u = p + 3 * e;
+                    const float* v = p + 3 * ((e + 1) % 3);
+                    if (u[ax] >= c0 && u[ax] <= c1) for (int a = 0; a < 3; a++) { b.lo[a] = fminf(b.lo[a], u[a]); b.hi[a] = fmaxf(b.hi[a], u[a]); }
+                    for (int side = 0; side < 2; side++) {
+                        const float c = side ? c1 : c0;
+                        if ((u[ax] < c && v[ax] > c) || (u[ax] > c && v[ax] < c)) {
+                            const float t = (c - u[ax]) / (v[ax] - u[ax]);
+                            for (int a = 0; a < 3; a++) {
+                                const float x = a == ax ? c : u[a] + (v[a] - u[a]) * t;
+                                b.lo[a] = fminf(b.lo[a], x); b.hi[a] = fmaxf(b.hi[a], x);
+                            }
+                        }
+                    }
+                }
+                if (!(b.lo[0] <= b.hi[0])) { for (int a = 0; a < 3; a++) { b.lo[a] = lo[a]; b.hi[a] = hi[a]; } }     // (cannot happen: every slab meets the triangle)
+                for (int a = 0; a < 3; a++) { b.lo[a] = fmaxf(b.lo[a], lo[a]); b.hi[a] = fminf(b.hi[a], hi[a]); }
+            }
+            for (int a = 0; a < 3; a++) {
+                b.lo[a] -= pad; b.hi[a] += pad;
+                const float c = 0.5f * (b.lo[a] + b.hi[a]);
+                cmn[a] = fminf(cmn[a], c); cmx[a] = fmaxf(cmx[a], c);
+            }
+            boxes[f + j] = b;
+            ref_prim[f + j] = i;
+        }
+    }
+    for (int a = 0; a < 3; a++) {
+        float mn = cmn[a], mx = cmx[a];
+        for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
+        if ((threadIdx.x & 63) == 0 && mn <= mx) { atomicMin(&bounds[a], f2ord(mn)); atomicMax(&bounds[3 + a], f2ord(mx)); }
+    }
+}
+
 #define HC(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { snprintf(err, errlen, "%s failed: %s", #x, hipGetErrorString(e_)); goto fail; } } while (0)
 
 }  // namespace
 
-hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* mesh_of_prim, uint32_t n, int use_ploc,
+hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* mesh_of_prim, uint32_t n_prims, int use_ploc, float split_budget,
                             BvhBuildResult* out, char* err, size_t errlen)
 {
+    uint32_t n = n_prims;                      // build primitives: triangles, or references of triangles when splits are on
+    uint32_t *ref_prim = nullptr, *split_cnt = nullptr, *split_first = nullptr;
+    unsigned long long* split_total = nullptr;
+    void* split_temp = nullptr;
     Box *boxes = nullptr, *ibox = nullptr;
     uint32_t *bounds = nullptr, *vals = nullptr, *vals_s = nullptr, *arrive = nullptr, *stats = nullptr;
     uint64_t *keys = nullptr, *keys_s = nullptr;
@@ -535,19 +631,61 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
     uint32_t* counters = nullptr;
     BvhNode4* nodes = nullptr;
     TriRec* tris = nullptr;
-    const uint32_t ni = n > 1 ? n - 1 : 1;
     const int B = 256;
-    const uint32_t gn = (n + B - 1) / B, gi = (ni + B - 1) / B;
+    uint32_t ni = 1, gn = 1, gi = 1;           // (assigned once the number of build primitives is known)
+    bool have_boxes = false;
     uint32_t h_bounds[6];
     uint32_t h_stats[2] = {0, 0};
     uint32_t h_counters[2] = {1, 0};
     hipError_t rc = hipSuccess;
     err[0] = 0;
     for (int a = 0; a < 3; a++) { h_bounds[a] = 0xffffffffu; h_bounds[3 + a] = 0u; }
-
-    HC(hipMalloc(&boxes, sizeof(Box) * n));
-    HC(hipMalloc(&ibox, sizeof(Box) * ni));
     HC(hipMalloc(&bounds, 6 * 4));
+    if (split_budget > 0.f && n_prims > FOVPT_LEAF_MAX) {
+        // how long may a box be before it is cut: bisection on s for (1 + budget) x n_prims references
+        const uint32_t gp = (n_prims + B - 1) / B;
+        unsigned long long h_total = 0, want = (unsigned long long)((double)n_prims * (1.0 + (double)split_budget));
+        HC(hipMalloc(&split_total, 8));
+        HC(hipMemcpyAsync(bounds, h_bounds, sizeof(h_bounds), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_scene_extent, dim3(gp), dim3(B), 0, st, flat, n_prims, bounds);
+        uint32_t hb[6];
+        HC(hipMemcpyAsync(hb, bounds, sizeof(hb), hipMemcpyDeviceToHost, st));
+        HC(hipStreamSynchronize(st));
+        float hi_s = 0.f;
+        for (int a = 0; a < 3; a++) hi_s = fmaxf(hi_s, ord2f(hb[3 + a]) - ord2f(hb[a]));
+        float lo_s = hi_s * 1e-7f, s_cut = hi_s;
+        for (int it = 0; it < 24 && hi_s > 0.f; it++) {
+            const float mid = sqrtf(lo_s * hi_s);                   // the extents span orders of magnitude
+            HC(hipMemsetAsync(split_total, 0, 8, st));
+            hipLaunchKernelGGL(k_split_count, dim3(gp), dim3(B), 0, st, flat, n_prims, mid, (uint32_t*)nullptr, split_total);
+            HC(hipMemcpyAsync(&h_total, split_total, 8, hipMemcpyDeviceToHost, st));
+            HC(hipStreamSynchronize(st));
+            if (h_total > want) lo_s = mid; else { hi_s = mid; s_cut = mid; }       // (the count falls as s grows)
+        }
+        HC(hipMalloc(&split_cnt, 4ull * n_prims)); HC(hipMalloc(&split_first, 4ull * n_prims));
+        HC(hipMemsetAsync(split_total, 0, 8, st));
+        hipLaunchKernelGGL(k_split_count, dim3(gp), dim3(B), 0, st, flat, n_prims, s_cut, split_cnt, split_total);
+        HC(hipMemcpyAsync(&h_total, split_total, 8, hipMemcpyDeviceToHost, st));
+        HC(hipStreamSynchronize(st));
+        if (h_total > n_prims && h_total < (1ull << 27)) {
+            size_t tb = 0;
+            HC(rocprim::exclusive_scan(nullptr, tb, split_cnt, split_first, 0u, (size_t)n_prims, rocprim::plus<uint32_t>(), st));
+            HC(hipMalloc(&split_temp, tb));
+            HC(rocprim::exclusive_scan(split_temp, tb, split_cnt, split_first, 0u, (size_t)n_prims, rocprim::plus<uint32_t>(), st));
+            n = (uint32_t)h_total;
+            HC(hipMalloc(&boxes, sizeof(Box) * n));
+            HC(hipMalloc(&ref_prim, 4ull * n));
+            HC(hipMemcpyAsync(bounds, h_bounds, sizeof(h_bounds), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL(k_split_emit, dim3(gp), dim3(B), 0, st, flat, n_prims, split_cnt, split_first, boxes, ref_prim, bounds);
+            HC(hipGetLastError());
+            have_boxes = true;
+        }
+    }
+    ni = n > 1 ? n - 1 : 1;
+    gn = (n + B - 1) / B; gi = (ni + B - 1) / B;
+
+    if (!have_boxes) HC(hipMalloc(&boxes, sizeof(Box) * n));
+    HC(hipMalloc(&ibox, sizeof(Box) * ni));
     HC(hipMalloc(&stats, 2 * 4));
     HC(hipMalloc(&counters, 2 * 4));
     HC(hipMalloc(&keys, 8ull * n)); HC(hipMalloc(&keys_s, 8ull * n));
@@ -557,10 +695,11 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
     HC(hipMalloc(&size_int, 4ull * ni)); HC(hipMalloc(&leaf_pos, 4ull * n)); HC(hipMalloc(&node_first, 4ull * ni));
     HC(hipMalloc(&nodes, sizeof(BvhNode4) * ni));              // a wide node replaces >= 1 binary node
     HC(hipMalloc(&tris, sizeof(TriRec) * n));
-    HC(hipMemcpyAsync(bounds, h_bounds, sizeof(h_bounds), hipMemcpyHostToDevice, st));
     HC(hipMemsetAsync(stats, 0, 8, st));
-
-    hipLaunchKernelGGL(k_tri_bounds, dim3(gn), dim3(B), 0, st, flat, n, boxes, bounds);
+    if (!have_boxes) {
+        HC(hipMemcpyAsync(bounds, h_bounds, sizeof(h_bounds), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_tri_bounds, dim3(gn), dim3(B), 0, st, flat, n, boxes, bounds);
+    }
     if (n <= FOVPT_LEAF_MAX) {
         hipLaunchKernelGGL(k_iota, dim3(1), dim3(64), 0, st, vals_s, n);
         hipLaunchKernelGGL(k_emit_tiny, dim3(1), dim3(1), 0, st, (int)n, boxes, nodes, stats, leaf_pos);
@@ -651,7 +790,7 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
             if (++levels > 4096) { snprintf(err, errlen, "BVH collapse did not terminate"); goto fail; }
         }
     }
-    hipLaunchKernelGGL(k_emit_tris_generic, dim3(gn), dim3(B), 0, st, flat, mesh_of_prim, vals_s, leaf_pos, n, tris);
+    hipLaunchKernelGGL(k_emit_tris_generic, dim3(gn), dim3(B), 0, st, flat, mesh_of_prim, vals_s, ref_prim, leaf_pos, n, tris);
     HC(hipGetLastError());
     HC(hipMemcpyAsync(h_stats, stats, 8, hipMemcpyDeviceToHost, st));
     HC(hipStreamSynchronize(st));
@@ -674,12 +813,14 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
         }
         out->nodes = (BvhNode4*)scene; out->tris = (TriRec*)(scene + tri_off);      // tris is INSIDE the nodes allocation
         out->num_nodes = h_stats[1];
+        out->num_refs = n;
         out->max_depth = h_stats[0];
         out->node_bytes = node_bytes;
         out->tri_bytes = tri_bytes;
     }
 fail:
     if (err[0]) rc = hipErrorUnknown;
+    (void)hipFree(ref_prim); (void)hipFree(split_cnt); (void)hipFree(split_first); (void)hipFree(split_total); (void)hipFree(split_temp);
     (void)hipFree(boxes); (void)hipFree(ibox); (void)hipFree(bounds); (void)hipFree(stats); (void)hipFree(keys); (void)hipFree(keys_s);
     (void)hipFree(vals); (void)hipFree(vals_s); (void)hipFree(arrive); (void)hipFree(left); (void)hipFree(right); (void)hipFree(parent_int);
     (void)hipFree(parent_leaf); (void)hipFree(rfirst); (void)hipFree(rlast); (void)hipFree(temp); (void)hipFree(nodes); (void)hipFree(tris);

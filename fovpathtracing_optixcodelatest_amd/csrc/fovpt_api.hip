@@ -11,6 +11,9 @@
 #include <vector>
 
 #include "fovpt_device.h"
+#ifndef FOVPT_SPLIT_BUDGET_DEFAULT
+#define FOVPT_SPLIT_BUDGET_DEFAULT 0.0f
+#endif
 #include <dlfcn.h>
 #include <rccl/rccl.h>      // types only: the library is loaded at run time (fovpt_comm_*), libfovpt.so does not link it
 
@@ -641,7 +644,10 @@ int fovpt_set_scene(fovpt_ctx* c, const fovpt_mesh_desc* meshes, int num_meshes,
     char errbuf[256];
     const char* bvh_env = getenv("FOVPT_BVH");          // "lbvh" = plain Karras tree (A/B testing); default PLOC
     const int use_ploc = !(bvh_env && strcmp(bvh_env, "lbvh") == 0);
-    hipError_t be = fovpt_build_lbvh(c->stream, d_flat, d_mesh_of, (uint32_t)ntri, use_ploc, &br, errbuf, sizeof(errbuf));
+    float split_budget = FOVPT_SPLIT_BUDGET_DEFAULT;    // references added by spatial splits, as a fraction of the triangles
+    if (const char* sb = getenv("FOVPT_SPLIT")) split_budget = (float)atof(sb);
+    if (!(split_budget >= 0.f) || split_budget > 2.f) split_budget = 0.f;
+    hipError_t be = fovpt_build_lbvh(c->stream, d_flat, d_mesh_of, (uint32_t)ntri, use_ploc, split_budget, &br, errbuf, sizeof(errbuf));
     (void)hipEventRecord(e1, c->stream);
     (void)hipEventSynchronize(e1);
     float ms = 0.f;
@@ -657,7 +663,7 @@ int fovpt_set_scene(fovpt_ctx* c, const fovpt_mesh_desc* meshes, int num_meshes,
                     (unsigned long long)(br.node_bytes + br.tri_bytes));
     }
     c->nodes = br.nodes; c->tris = br.tris;
-    c->num_tris = (uint32_t)ntri;
+    c->num_tris = br.num_refs;                       // triangle RECORDS (>= the triangles when some were split into references)
     c->has_scene = true;
     c->scene_id = (c->scene_id & 0xffffffffull) + 1;
     c->scene_id |= 0x464f565000000000ull;          // 'FOVP' tag so a stale/foreign handle is recognisable

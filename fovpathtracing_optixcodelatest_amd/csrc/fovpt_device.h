@@ -185,12 +185,14 @@ struct BvhBuildResult {
     BvhNode4* nodes;              // ONE allocation: the emitted nodes, then (256-byte aligned) the triangles; free `nodes` only
     TriRec* tris;
     uint32_t num_nodes;           // wide nodes emitted (breadth-first order, root = 0)
+    uint32_t num_refs;            // triangle records behind the nodes: the triangles, or more when triangles were split into references
     uint32_t max_depth;
     size_t node_bytes, tri_bytes;
 };
 
 // flat: 9 floats per triangle (v0,v1,v2), mesh_of_prim: mesh id per triangle.  All device pointers.
-hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* mesh_of_prim, uint32_t n, int use_ploc,
+// split_budget: references added by spatial splits as a fraction of the triangles (0 = none), see bvh_build.hip.
+hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* mesh_of_prim, uint32_t n, int use_ploc, float split_budget,
                             BvhBuildResult* out, char* err, size_t errlen);
 
 // cap = shard capacity (in items) of the radiance queues and of the shadow queue.

@@ -242,6 +242,43 @@ def test_cpp_host_gathers_over_rccl(tmp_path):
     assert np.array_equal(px[0], px[1]), res.stdout
 
 
+@pytest.mark.parametrize("budget", ["0.3", "1.0"])
+def test_spatial_splits_do_not_change_the_frame(oracle, budget, monkeypatch):
+    """Spatial splits in the hierarchy build (FOVPT_SPLIT: long triangles enter the build as several references, each a leaf
+    record of the WHOLE triangle with its global primitive id -- replaces part of optixAccelBuild, SimplePathtracer.cpp:677-735):
+    a ray may test a triangle more than once, and closest hit (minimum (t, primitive id)), the occlusion predicate, the frame
+    and the ray counts stay what they are.  Scene: the hall plus four triangles that span it."""
+    size = (160, 96)
+    hall = scenes.atrium(6000)
+    v = np.concatenate([m.vertex for m in hall.meshes])
+    lo, hi = v.min(0), v.max(0)
+    big = np.float32([[lo[0], lo[1] + 1.0, lo[2]], [hi[0], lo[1] + 1.0, lo[2]], [hi[0], lo[1] + 1.0, hi[2]], [lo[0], lo[1] + 1.0, hi[2]],
+                      [lo[0], lo[1], lo[2]], [hi[0], hi[1], hi[2]], [lo[0], hi[1], hi[2]]])
+    model = scenes.Model(list(hall.meshes) + [scenes.TriangleMesh(big, np.uint32([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 5]]), scenes.matte((0.6, 0.6, 0.5)))],
+                         list(hall.textures))
+    cfg = cfg_foveated(12, 40, (1, 2, 4))
+    probe = scenes.sky_probe(64, 32, seed=9)
+    r = make_gpu(model, probe, scenes.ATRIUM_CAMERA, size, cfg)
+    r.render()
+    want_a, want_f, st0 = r.downloadAccum(), r.downloadPixels(), r.stats()
+    o, d = np.float32([[0, 100, 0]] * 3), np.float32([[0, -1, 0], [1, 0, 0], [0.577, 0.577, 0.577]])
+    p0 = r.debug_trace(o, d)
+    r.close()
+    monkeypatch.setenv("FOVPT_SPLIT", budget)
+    r = make_gpu(model, probe, scenes.ATRIUM_CAMERA, size, cfg)
+    r.render()
+    got_a, got_f, st1 = r.downloadAccum(), r.downloadPixels(), r.stats()
+    p1 = r.debug_trace(o, d)
+    r.close()
+    assert st1.num_triangles == st0.num_triangles                       # the scene is the same; the build saw more references
+    assert np.array_equal(got_a.view(np.uint32), want_a.view(np.uint32)) and np.array_equal(got_f, want_f)
+    assert (st1.paths, st1.radiance_rays, st1.shadow_rays) == (st0.paths, st0.radiance_rays, st0.shadow_rays)
+    assert np.array_equal(p0[0], p1[0]) and np.array_equal(p0[1].view(np.uint32), p1[1].view(np.uint32)) and np.array_equal(p0[2], p1[2])
+    S, F = make_oracle(oracle, model, probe, scenes.ATRIUM_CAMERA, size)
+    oracle.render(S, F, cfg)
+    assert np.array_equal(got_f, F.frame)
+
+
 def _write_textured_obj(tmp_path):
     rng = np.random.default_rng(4)
     tex = rng.integers(0, 256, (8, 8, 3), dtype=np.uint8)

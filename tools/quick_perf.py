@@ -7,12 +7,13 @@ from fovpathtracing_optixcodelatest_amd import abi, renderer, scenes
 W, H = 1920, 1080
 ntri = int(sys.argv[1]) if len(sys.argv) > 1 else 262144
 frames = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-t = time.time(); model = scenes.atrium(ntri); print("scene", model.num_triangles, "tris", round(time.time() - t, 2), "s")
+street = os.environ.get("FOVPT_SCENE") == "street"
+t = time.time(); model = scenes.street(ntri, material="app") if street else scenes.atrium(ntri); print("scene", model.num_triangles, "tris", round(time.time() - t, 2), "s")
 t = time.time(); r = renderer.SampleRenderer(model); print("set_scene", round(time.time() - t, 2), "s")
 r.resize((W, H))
-cam = scenes.ATRIUM_CAMERA
+cam = scenes.STREET_CAMERA if street else scenes.ATRIUM_CAMERA
 r.setCamera(renderer.Camera(cam["eye"], cam["lookat"], cam["up"], cam["fovy"], W / H))
-t = time.time(); r.setProbe(renderer.ProbeData(scenes.ambient_probe(W, H, 2.5)).BuildCDF()); print("probe", round(time.time() - t, 2), "s")
+t = time.time(); r.setProbe(renderer.ProbeData(scenes.sky_probe(W, H, seed=11) if street else scenes.ambient_probe(W, H, 2.5)).BuildCDF()); print("probe", round(time.time() - t, 2), "s")
 cfg = abi.Config.reference_default()
 cfg.r_inner, cfg.r_outer = 148, 482
 cfg.spp_periphery, cfg.spp_middle, cfg.spp_fovea = 1, 2, 8
