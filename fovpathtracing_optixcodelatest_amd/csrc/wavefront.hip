@@ -606,8 +606,9 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, Pat
 // (so a node visit is one box test deep instead of four), on a leaf lane j tests triangle j; the four
 // results meet through the wave ballot and DPP quad permutes (register to register).  A wave thus
 // carries 16 rays, each step is ~3x shorter than with one lane per ray, and divergence is between 16
-// rays instead of 64.  The vector ALU is what a step costs, so the steps are
-// written instruction by instruction.
+// rays instead of 64.  A step is one link of a serial chain per wave -- ~1000 cycles, ~60 % of them the wait for the two node
+// loads of the wave's slowest quad, the rest the wave's own ~45 instructions (measured with s_memtime stamps,
+// profiles/r03_step_cycles.txt) -- so the steps are written instruction by instruction.
 struct RayT {
     float ox, oy, oz, dx, dy, dz;
     float ix, iy, iz;          // safe reciprocal direction for the box test
@@ -668,7 +669,7 @@ __device__ inline TriRec load_tri_off(const TriRec* __restrict__ tris, uint32_t 
 // identical in the four lanes; each lane keeps the best hit among the triangles IT tested and the
 // four are merged once, at the end, by (t, primitive id) -- the same total order as a sequential scan.
 //
-// A node step is issue-bound, so it is kept short: the hit mask of the quad comes out of the wave
+// A node step sits on the wave's dependent chain (load -> test -> rank -> stack -> pop -> load), so it is kept short: the hit mask of the quad comes out of the wave
 // ballot (one shift), every hit lane stores its child at stack[sp + H-1-rank] and the next node is
 // simply popped -- descending and backtracking are the same code, no cross-lane selects.
 __device__ inline uint32_t quad_rot1(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x39, 0xf, 0xf, true); }   // [1,2,3,0]
@@ -679,6 +680,13 @@ enum { ROWB = FOVPT_TQUADS * 4,                 // byte distance of two stack ro
        ROWSHIFT = FOVPT_TQUADS == 64 ? 8 : 10 };
 static_assert(FOVPT_LEAF_MAX <= 4, "a leaf is tested in one quad step");
 static_assert(FOVPT_TQUADS == 64 || FOVPT_TQUADS == 256, "row stride of the stack is 256 or 1024 bytes");
+
+// The traversal stack lives in LDS and is addressed through pointers that SAY so (address space 3, 32 bits): every access is a
+// ds_read / ds_write by construction.  With a generic `char*` that held only as long as the compiler could infer the address
+// space; a build in which it cannot (the stack pointer loaded back from memory, as with a run-time-indexed private array next
+// to it -- round 2's faulting diagnostic build) would fall back to flat accesses on a 64-bit pointer.
+typedef __attribute__((address_space(3))) char LdsChar;
+typedef __attribute__((address_space(3))) int LdsInt;
 
 struct QuadLane {                                   // per-lane constants of the quad traversal
     uint32_t j, qshift, from_me, j32, j3;
@@ -694,7 +702,7 @@ struct QuadLane {                                   // per-lane constants of the
 };
 struct QuadTrav {                                   // state of one ray's traversal (identical in the 4 lanes except the best hit)
     int cur;                                        // node >= 0, leaf < 0, TRAV_DONE
-    char* top;                                      // byte address of the first free stack row
+    LdsChar* top;                                   // LDS byte address of the first free stack row
     float lim;                                      // closest: prunes boxes beyond the quad-wide best hit
     float bt, bu, bv; uint32_t bpos, bprim;         // best hit among the triangles THIS lane tested
 #if FOVPT_V_STEPSTAT
@@ -706,7 +714,7 @@ struct QuadTrav {                                   // state of one ray's traver
     __device__ inline void start(int* stack, const QuadLane& q)
     {
         if (q.j == 0) stack[0] = TRAV_DONE;
-        top = (char*)stack + ROWB;
+        top = (LdsChar*)(LdsInt*)stack + ROWB;
         cur = 0; lim = TMAX;
         bt = INFINITY; bu = 0.f; bv = 0.f; bpos = 0xffffffffu; bprim = 0xffffffffu;
     }
@@ -798,10 +806,10 @@ __device__ inline void node_step(const SceneView& sc, const RayT& r, const QuadL
 #if FOVPT_V_CYCLES
     if (C.on) c2 = cyc_stamp(row, Hm1);
 #endif
-    *(int*)(T.top + row) = code;
+    *(LdsInt*)(T.top + row) = code;
     T.top += Hm1 * ROWB;                        // H pushed, one popped
     __builtin_amdgcn_wave_barrier();
-    T.cur = *(const int*)T.top;
+    T.cur = *(const LdsInt*)T.top;
 #if FOVPT_V_CYCLES
     if (C.on) {
         const uint32_t c3 = cyc_stamp(T.cur);
@@ -863,7 +871,7 @@ __device__ inline bool leaf_step(const SceneView& sc, const RayT& r, const QuadL
         T.lim = fminf(TMAX, __uint_as_float(m) * 1.000001f);
     }
     T.top -= ROWB;
-    T.cur = *(const int*)T.top;
+    T.cur = *(const LdsInt*)T.top;
     CYC_LEAF_END(T.cur);
     return false;
 }
@@ -897,7 +905,7 @@ __device__ inline void store_shadow(const PathState& ps, const ShadowQueue& sq, 
 // identical in the four lanes; each lane keeps the best hit among the triangles IT tested and the
 // four are merged once, at the end, by (t, primitive id) -- the same total order as a sequential scan.
 //
-// A node step is issue-bound, so it is kept short: the hit mask of the quad comes out of the wave
+// A node step sits on the wave's dependent chain (load -> test -> rank -> stack -> pop -> load), so it is kept short: the hit mask of the quad comes out of the wave
 // ballot (one shift), every lane stores its child at a row derived from its rank and the next node is
 // simply popped -- descending and backtracking are the same code, no cross-lane selects.
 __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __restrict__ stack /* [e * QUADS_PER_BLOCK] */, const QuadLane& q,
