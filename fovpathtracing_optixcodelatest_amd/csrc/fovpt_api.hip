@@ -921,6 +921,7 @@ int fovpt_gather_unpack(fovpt_ctx* c, const uint32_t* gathered, uint32_t stride,
 // all enqueued on fovpt_stream(), the stream frames complete on: no host synchronisation, and the transport of frame k runs
 // beside the rendering of frame k + 1.  librccl is loaded at run time so that libfovpt.so has no link-time dependency on it
 // (a process that already holds an RCCL -- PyTorch's -- gets that one: same SONAME).
+}  // extern "C"
 namespace {
 struct Rccl {
     void* lib = nullptr;
@@ -960,6 +961,7 @@ Rccl& rccl()
 }
 #define NCCLCHK(c, x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) return fail((c), FOVPT_E_DEVICE, "%s: %s", #x, rccl().GetErrorString(r_)); } while (0)
 }  // namespace
+extern "C" {
 
 int fovpt_comm_get_unique_id(void* id)
 {

@@ -26,6 +26,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <map>
 #include <new>
 #include <exception>
@@ -621,6 +622,138 @@ fovpt_material reference_default_material()     // Material.h:48-69, the values 
     return m;
 }
 
+// ---- glTF 2.0 (.gltf with external or data-URI buffers, .glb) -> meshes in world space with the traversal rules of
+// sutil::Scene (sutil/Scene.cpp:109-442): roots are the nodes without a parent; a node's transform is
+// parent * matrix * T * R * S in binary32 (:148, sutil::Matrix<4,4>::operator* sums k = 0..3 from 0, Matrix.h:339-355; the
+// quaternion as given, sutil/Quaternion.h:239-269); a camera node is skipped with its subtree (:150-180); below a mesh node
+// nothing is visited (:181-196); triangle primitives only (:327-331); base colour / roughness / metallic factors and the base
+// colour texture (:281-317).  The reference keeps object-space vertices and instances them; here every primitive becomes one
+// mesh in world space: p' = ((m0 x + m1 y) + m2 z) + m3 (Matrix.h:467-485 with w = 1).  Same arithmetic, in the same order, as
+// loaders.load_gltf (python), which tests/test_loaders_cpu.py holds this against bit for bit.
+struct Json {
+    enum Kind { Null, Bool, Num, Str, Arr, Obj } kind = Null;
+    bool b = false;
+    double num = 0.0;
+    std::string str;
+    std::vector<Json> arr;
+    std::vector<std::pair<std::string, Json>> obj;
+    const Json* get(const char* key) const
+    {
+        if (kind != Obj) return nullptr;
+        for (const auto& kv : obj) if (kv.first == key) return &kv.second;
+        return nullptr;
+    }
+    double number(const char* key, double dflt) const { const Json* v = get(key); return v && v->kind == Num ? v->num : dflt; }
+    long integer(const char* key, long dflt) const { const Json* v = get(key); return v && v->kind == Num ? (long)v->num : dflt; }
+};
+struct JsonParser {
+    const char* p; const char* end; int depth = 0;
+    void ws() { while (p < end && (*p == ' ' || *p == '\t' || *p == '\n' || *p == '\r')) p++; }
+    bool lit(const char* t) { const size_t n = strlen(t); if ((size_t)(end - p) >= n && !memcmp(p, t, n)) { p += n; return true; } return false; }
+    static void utf8(std::string& o, unsigned c)
+    {
+        if (c < 0x80) o += (char)c;
+        else if (c < 0x800) { o += (char)(0xC0 | (c >> 6)); o += (char)(0x80 | (c & 63)); }
+        else if (c < 0x10000) { o += (char)(0xE0 | (c >> 12)); o += (char)(0x80 | ((c >> 6) & 63)); o += (char)(0x80 | (c & 63)); }
+        else { o += (char)(0xF0 | (c >> 18)); o += (char)(0x80 | ((c >> 12) & 63)); o += (char)(0x80 | ((c >> 6) & 63)); o += (char)(0x80 | (c & 63)); }
+    }
+    bool string(std::string& o)
+    {
+        if (p >= end || *p != '"') return false;
+        p++;
+        while (p < end && *p != '"') {
+            if (*p == '\\') {
+                if (++p >= end) return false;
+                const char c = *p++;
+                if (c == 'n') o += '\n'; else if (c == 't') o += '\t'; else if (c == 'r') o += '\r'; else if (c == 'b') o += '\b'; else if (c == 'f') o += '\f';
+                else if (c == 'u') {
+                    auto hex4 = [&](unsigned& v) { if (end - p < 4) return false; v = 0; for (int k = 0; k < 4; k++) { const char h = *p++; v = v * 16 + (unsigned)(h >= '0' && h <= '9' ? h - '0' : (h | 32) >= 'a' && (h | 32) <= 'f' ? (h | 32) - 'a' + 10 : 0); } return true; };
+                    unsigned cp = 0;
+                    if (!hex4(cp)) return false;
+                    if (cp >= 0xD800 && cp < 0xDC00 && end - p >= 6 && p[0] == '\\' && p[1] == 'u') { p += 2; unsigned lo = 0; if (!hex4(lo)) return false; cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00); }
+                    utf8(o, cp);
+                } else o += c;                                   // \" \\ \/
+            } else o += *p++;
+        }
+        if (p >= end) return false;
+        p++;
+        return true;
+    }
+    bool value(Json& v)
+    {
+        if (++depth > 200) return false;
+        ws();
+        if (p >= end) return false;
+        bool ok = true;
+        if (*p == '{') {
+            v.kind = Json::Obj; p++; ws();
+            if (p < end && *p == '}') p++;
+            else for (;;) {
+                ws();
+                std::string k;
+                if (!string(k)) { ok = false; break; }
+                ws();
+                if (p >= end || *p++ != ':') { ok = false; break; }
+                v.obj.emplace_back(std::move(k), Json());
+                if (!value(v.obj.back().second)) { ok = false; break; }
+                ws();
+                if (p < end && *p == ',') { p++; continue; }
+                if (p < end && *p == '}') { p++; break; }
+                ok = false; break;
+            }
+        } else if (*p == '[') {
+            v.kind = Json::Arr; p++; ws();
+            if (p < end && *p == ']') p++;
+            else for (;;) {
+                v.arr.emplace_back();
+                if (!value(v.arr.back())) { ok = false; break; }
+                ws();
+                if (p < end && *p == ',') { p++; continue; }
+                if (p < end && *p == ']') { p++; break; }
+                ok = false; break;
+            }
+        } else if (*p == '"') { v.kind = Json::Str; ok = string(v.str); }
+        else if (lit("true")) { v.kind = Json::Bool; v.b = true; }
+        else if (lit("false")) { v.kind = Json::Bool; v.b = false; }
+        else if (lit("null")) v.kind = Json::Null;
+        else {
+            const char* q = p;
+            while (q < end && (isdigit((unsigned char)*q) || *q == '-' || *q == '+' || *q == '.' || *q == 'e' || *q == 'E')) q++;
+            if (q == p) ok = false;
+            else { const std::string t(p, q); char* e = nullptr; v.kind = Json::Num; v.num = strtod(t.c_str(), &e); ok = e && *e == 0; p = q; }
+        }
+        depth--;
+        return ok;
+    }
+};
+
+struct M4 { float m[16]; };            // row-major, as sutil::Matrix<4,4>
+M4 m4_identity() { M4 r; for (int k = 0; k < 16; k++) r.m[k] = (k % 5 == 0) ? 1.f : 0.f; return r; }
+M4 m4_mul(const M4& a, const M4& b)    // Matrix.h:339-355
+{
+    M4 r;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            float sum = 0.0f;
+            for (int k = 0; k < 4; k++) { const float ik = a.m[i * 4 + k], kj = b.m[k * 4 + j]; sum += ik * kj; }
+            r.m[i * 4 + j] = sum;
+        }
+    return r;
+}
+
+bool b64_decode(const std::string& in, std::vector<uint8_t>& out)
+{
+    unsigned acc = 0; int bits = 0;
+    for (const char ch : in) {
+        int v;
+        if (ch >= 'A' && ch <= 'Z') v = ch - 'A'; else if (ch >= 'a' && ch <= 'z') v = ch - 'a' + 26; else if (ch >= '0' && ch <= '9') v = ch - '0' + 52;
+        else if (ch == '+') v = 62; else if (ch == '/') v = 63; else continue;          // '=' padding and anything else is skipped
+        acc = (acc << 6) | (unsigned)v; bits += 6;
+        if (bits >= 8) { bits -= 8; out.push_back((uint8_t)((acc >> bits) & 255u)); }
+    }
+    return true;
+}
+
 }  // namespace
 
 struct fovpt_model {
@@ -752,6 +885,239 @@ static int model_load_obj_impl(const char* obj_file, fovpt_model** out)
             model->meshes.push_back(std::move(mesh));
         }
     }
+    *out = model.release();
+    return FOVPT_OK;
+}
+
+static int model_load_gltf_impl(const char* file, fovpt_model** out);
+int fovpt_model_load_gltf(const char* file, fovpt_model** out)
+{
+    if (out) *out = nullptr;
+    return guarded("fovpt_model_load_gltf", [&]() { return model_load_gltf_impl(file, out); });
+}
+static int model_load_gltf_impl(const char* file, fovpt_model** out)
+{
+    if (!file || !out) { fovpt_internal_set_error("fovpt_model_load_gltf: null argument"); return FOVPT_E_INVALID; }
+    const std::string path = file;
+    auto bad = [&](const std::string& why) { fovpt_internal_set_error(("Could not read glTF scene from " + path + " : " + why).c_str()); return FOVPT_E_INVALID; };
+    const size_t slash = path.find_last_of("/\\");
+    const std::string dir = slash == std::string::npos ? std::string() : path.substr(0, slash + 1);
+    std::vector<uint8_t> raw;
+    if (!read_file(path, raw)) return bad("cannot open file");
+    std::vector<uint8_t> glb_bin;
+    bool have_glb_bin = false;
+    std::string text;
+    if (raw.size() >= 12 && !memcmp(raw.data(), "glTF", 4)) {              // binary container: header, JSON chunk, optional BIN chunk
+        auto le32 = [&](size_t o) { return (uint32_t)raw[o] | ((uint32_t)raw[o + 1] << 8) | ((uint32_t)raw[o + 2] << 16) | ((uint32_t)raw[o + 3] << 24); };
+        const uint32_t version = le32(4), total = le32(8);
+        if (version != 2 || total > raw.size()) return bad("glb: unsupported version or truncated file");
+        size_t pos = 12;
+        bool first = true;
+        while (pos + 8 <= total) {
+            const uint32_t clen = le32(pos), ctype = le32(pos + 4);
+            const size_t body = pos + 8, avail = body <= raw.size() ? std::min<size_t>(clen, raw.size() - body) : 0;
+            if (first) {
+                if (ctype != 0x4E4F534Au) return bad("glb: the first chunk is not JSON");
+                text.assign((const char*)raw.data() + body, avail);
+                first = false;
+            } else if (ctype == 0x004E4942u && !have_glb_bin) { glb_bin.assign(raw.begin() + body, raw.begin() + body + avail); have_glb_bin = true; }
+            pos += 8 + (size_t)clen + ((4u - (clen & 3u)) & 3u);
+        }
+        if (first) return bad("glb: the first chunk is not JSON");
+    } else text.assign((const char*)raw.data(), raw.size());
+    Json g;
+    { JsonParser P{text.data(), text.data() + text.size()}; if (!P.value(g) || g.kind != Json::Obj) return bad("not a JSON object"); }
+    static const Json empty_arr = [] { Json j; j.kind = Json::Arr; return j; }();
+    auto list = [&](const Json& o, const char* key) -> const Json& { const Json* v = o.get(key); return v && v->kind == Json::Arr ? *v : empty_arr; };
+
+    // buffers
+    std::vector<std::vector<uint8_t>> buffers;
+    const Json& jbuf = list(g, "buffers");
+    for (size_t k = 0; k < jbuf.arr.size(); k++) {
+        const Json* uri = jbuf.arr[k].get("uri");
+        std::vector<uint8_t> data;
+        if (uri && uri->kind == Json::Str) {
+            if (uri->str.compare(0, 5, "data:") == 0) {
+                const size_t comma = uri->str.find(',');
+                if (comma == std::string::npos) return bad("malformed data uri");
+                b64_decode(uri->str.substr(comma + 1), data);
+            } else if (!read_file(dir + uri->str, data)) return bad("cannot open buffer " + uri->str);
+        } else if (k == 0 && have_glb_bin) data = glb_bin;
+        else return bad("a buffer has no uri");
+        buffers.push_back(std::move(data));
+    }
+    const Json &jacc = list(g, "accessors"), &jviews = list(g, "bufferViews"), &jmeshes = list(g, "meshes"), &jnodes = list(g, "nodes"),
+               &jmats = list(g, "materials"), &jtex = list(g, "textures"), &jimg = list(g, "images");
+
+    // accessor -> rows of `nc` components as float (positions, texcoords) or uint32 (indices)
+    struct Acc { size_t count = 0; int nc = 0; std::vector<float> f; std::vector<uint32_t> u; };
+    auto accessor = [&](long idx, bool as_index, Acc& A) -> bool {
+        if (idx < 0 || (size_t)idx >= jacc.arr.size()) return false;
+        const Json& a = jacc.arr[idx];
+        const long ct = a.integer("componentType", 0);
+        const Json* ty = a.get("type");
+        if (!ty || ty->kind != Json::Str) return false;
+        const int nc = ty->str == "SCALAR" ? 1 : ty->str == "VEC2" ? 2 : ty->str == "VEC3" ? 3 : ty->str == "VEC4" ? 4 : ty->str == "MAT4" ? 16 : 0;
+        const size_t esz = ct == 5120 || ct == 5121 ? 1 : ct == 5122 || ct == 5123 ? 2 : ct == 5125 || ct == 5126 ? 4 : 0;
+        const long cnt = a.integer("count", -1);
+        if (!nc || !esz || cnt < 0 || cnt > (1l << 28)) return false;
+        A.count = (size_t)cnt; A.nc = nc;
+        const size_t n = A.count * (size_t)nc;
+        if (as_index) A.u.assign(n, 0u); else A.f.assign(n, 0.0f);
+        const Json* bvi = a.get("bufferView");
+        if (!bvi || bvi->kind != Json::Num) return true;                  // no bufferView: zeros
+        const long bi = (long)bvi->num;
+        if (bi < 0 || (size_t)bi >= jviews.arr.size()) return false;
+        const Json& bv = jviews.arr[bi];
+        const long buf = bv.integer("buffer", -1);
+        if (buf < 0 || (size_t)buf >= buffers.size()) return false;
+        const size_t off = (size_t)bv.integer("byteOffset", 0) + (size_t)a.integer("byteOffset", 0), elem = esz * (size_t)nc;
+        size_t stride = (size_t)bv.integer("byteStride", 0);
+        if (!stride) stride = elem;
+        const std::vector<uint8_t>& B = buffers[buf];
+        if (A.count && (off > B.size() || (A.count - 1) * stride + elem > B.size() - off)) return false;
+        const Json* nrm = a.get("normalized");
+        const bool normalized = nrm && nrm->kind == Json::Bool && nrm->b && ct != 5126;
+        for (size_t i = 0; i < A.count; i++)
+            for (int c = 0; c < nc; c++) {
+                const uint8_t* p = B.data() + off + i * stride + (size_t)c * esz;
+                double v; uint32_t uv = 0; float fv = 0.f;
+                switch (ct) {
+                case 5120: v = (double)(int8_t)p[0]; uv = (uint32_t)(int32_t)(int8_t)p[0]; break;
+                case 5121: v = (double)p[0]; uv = p[0]; break;
+                case 5122: { int16_t x; memcpy(&x, p, 2); v = (double)x; uv = (uint32_t)(int32_t)x; } break;
+                case 5123: { uint16_t x; memcpy(&x, p, 2); v = (double)x; uv = x; } break;
+                case 5125: { uint32_t x; memcpy(&x, p, 4); v = (double)x; uv = x; } break;
+                default: { memcpy(&fv, p, 4); v = (double)fv; uv = (uint32_t)fv; } break;
+                }
+                if (as_index) A.u[i * nc + c] = uv;
+                else if (ct == 5126) A.f[i * nc + c] = fv;
+                else if (normalized) {                                     // max(float(v) / float(max of the type), -1)
+                    const float scale = ct == 5120 ? 127.f : ct == 5121 ? 255.f : ct == 5122 ? 32767.f : ct == 5123 ? 65535.f : 4294967295.f;
+                    const float q = (float)v / scale;
+                    A.f[i * nc + c] = q < -1.0f ? -1.0f : q;
+                } else A.f[i * nc + c] = (float)v;
+            }
+        return true;
+    };
+
+    std::unique_ptr<fovpt_model> model(new fovpt_model);
+    std::map<long, int> tex_cache;
+    auto texture_id = [&](const Json* index) -> int {
+        if (!index || index->kind != Json::Num) return -1;
+        const long ti = (long)index->num;
+        auto it = tex_cache.find(ti);
+        if (it != tex_cache.end()) return it->second;
+        int tid = -1;
+        if (ti >= 0 && (size_t)ti < jtex.arr.size()) {
+            const long src = jtex.arr[ti].integer("source", -1);
+            if (src >= 0 && (size_t)src < jimg.arr.size()) {
+                const Json* uri = jimg.arr[src].get("uri");
+                if (uri && uri->kind == Json::Str && uri->str.compare(0, 5, "data:") != 0) {
+                    Image img;
+                    if (load_texture_file(dir + uri->str, img)) { model->textures.push_back(std::move(img)); tid = (int)model->textures.size() - 1; }
+                }
+            }
+        }
+        tex_cache[ti] = tid;
+        return tid;
+    };
+    auto vec = [&](const Json& o, const char* key, int n, const double* dflt, double* dst) {
+        const Json* v = o.get(key);
+        for (int k = 0; k < n; k++) dst[k] = (v && v->kind == Json::Arr && (size_t)k < v->arr.size() && v->arr[k].kind == Json::Num) ? v->arr[k].num : dflt[k];
+        return v && v->kind == Json::Arr;
+    };
+    auto material = [&](const Json* idx, fovpt_material& m, int& tid) {
+        m = reference_default_material();
+        m.emission = {0.f, 0.f, 0.f};
+        tid = -1;
+        if (!idx || idx->kind != Json::Num || idx->num < 0 || (size_t)idx->num >= jmats.arr.size()) return;
+        const Json& gm = jmats.arr[(size_t)idx->num];
+        static const Json empty_obj = [] { Json j; j.kind = Json::Obj; return j; }();
+        const Json* pbrp = gm.get("pbrMetallicRoughness");
+        const Json& pbr = pbrp && pbrp->kind == Json::Obj ? *pbrp : empty_obj;
+        const double one4[4] = {1, 1, 1, 1}, zero3[3] = {0, 0, 0};
+        double c[4], e[3];
+        vec(pbr, "baseColorFactor", 4, one4, c);
+        m.color = {(float)c[0], (float)c[1], (float)c[2]};
+        m.roughness = (float)pbr.number("roughnessFactor", 1.0);
+        m.metallic = (float)pbr.number("metallicFactor", 1.0);
+        vec(gm, "emissiveFactor", 3, zero3, e);
+        m.emission = {(float)e[0], (float)e[1], (float)e[2]};
+        const Json* bct = pbr.get("baseColorTexture");
+        if (bct && bct->kind == Json::Obj) tid = texture_id(bct->get("index"));
+    };
+
+    std::vector<char> is_root(jnodes.arr.size(), 1);
+    for (const Json& n : jnodes.arr)
+        for (const Json& ch : list(n, "children").arr)
+            if (ch.kind == Json::Num && ch.num >= 0 && (size_t)ch.num < is_root.size()) is_root[(size_t)ch.num] = 0;
+    std::string failure;
+    std::function<void(const Json&, const M4&, int)> visit = [&](const Json& node, const M4& parent, int depth) {
+        if (depth > 512 || !failure.empty()) return;
+        const double zero3[3] = {0, 0, 0}, one3[3] = {1, 1, 1}, ident_q[4] = {0, 0, 0, 1};
+        double t[3], r[4], sc[3];
+        M4 T = m4_identity(), R = m4_identity(), S = m4_identity(), M = m4_identity();
+        if (vec(node, "translation", 3, zero3, t)) { T.m[3] = (float)t[0]; T.m[7] = (float)t[1]; T.m[11] = (float)t[2]; }
+        if (vec(node, "rotation", 4, ident_q, r)) {                       // sutil::Quaternion(w, x, y, z).rotationMatrix()
+            const float qx = (float)r[0], qy = (float)r[1], qz = (float)r[2], qw = (float)r[3], one = 1.0f, two = 2.0f;
+            R.m[0] = one - two * qy * qy - two * qz * qz; R.m[1] = two * qx * qy - two * qz * qw; R.m[2] = two * qx * qz + two * qy * qw;
+            R.m[4] = two * qx * qy + two * qz * qw; R.m[5] = one - two * qx * qx - two * qz * qz; R.m[6] = two * qy * qz - two * qx * qw;
+            R.m[8] = two * qx * qz - two * qy * qw; R.m[9] = two * qy * qz + two * qx * qw; R.m[10] = one - two * qx * qx - two * qy * qy;
+        }
+        if (vec(node, "scale", 3, one3, sc)) { S.m[0] = (float)sc[0]; S.m[5] = (float)sc[1]; S.m[10] = (float)sc[2]; }
+        const Json* mm = node.get("matrix");
+        if (mm && mm->kind == Json::Arr && mm->arr.size() == 16)
+            for (int c = 0; c < 4; c++) for (int rr = 0; rr < 4; rr++) M.m[rr * 4 + c] = (float)mm->arr[c * 4 + rr].num;   // column-major in the file
+        const M4 xf = m4_mul(m4_mul(m4_mul(m4_mul(parent, M), T), R), S);
+        if (node.get("camera")) return;
+        const Json* mi = node.get("mesh");
+        if (mi && mi->kind == Json::Num) {
+            if (mi->num < 0 || (size_t)mi->num >= jmeshes.arr.size()) { failure = "a node references a mesh that does not exist"; return; }
+            for (const Json& prim : list(jmeshes.arr[(size_t)mi->num], "primitives").arr) {
+                if (prim.integer("mode", 4) != 4) continue;
+                const Json* attrs = prim.get("attributes");
+                const Json* jp = attrs ? attrs->get("POSITION") : nullptr;
+                if (!jp || jp->kind != Json::Num) { failure = "a primitive has no POSITION"; return; }
+                Acc pos;
+                if (!accessor((long)jp->num, false, pos) || pos.nc < 3) { failure = "bad POSITION accessor"; return; }
+                Mesh mesh;
+                mesh.vertex.resize(pos.count);
+                for (size_t i = 0; i < pos.count; i++) {
+                    const float x = pos.f[i * pos.nc], y = pos.f[i * pos.nc + 1], z = pos.f[i * pos.nc + 2];
+                    mesh.vertex[i] = {((xf.m[0] * x + xf.m[1] * y) + xf.m[2] * z) + xf.m[3],
+                                      ((xf.m[4] * x + xf.m[5] * y) + xf.m[6] * z) + xf.m[7],
+                                      ((xf.m[8] * x + xf.m[9] * y) + xf.m[10] * z) + xf.m[11]};
+                }
+                const Json* ji = prim.get("indices");
+                if (ji && ji->kind == Json::Num) {
+                    Acc ia;
+                    if (!accessor((long)ji->num, true, ia)) { failure = "bad index accessor"; return; }
+                    mesh.index = std::move(ia.u);
+                } else { mesh.index.resize(pos.count); for (size_t i = 0; i < pos.count; i++) mesh.index[i] = (uint32_t)i; }
+                mesh.index.resize(mesh.index.size() / 3 * 3);
+                const Json* jt = attrs->get("TEXCOORD_0");
+                bool has_tc = false;
+                if (jt && jt->kind == Json::Num) {
+                    Acc tc;
+                    if (!accessor((long)jt->num, false, tc) || tc.nc < 2) { failure = "bad TEXCOORD_0 accessor"; return; }
+                    mesh.texcoord.resize(tc.count);
+                    for (size_t i = 0; i < tc.count; i++) mesh.texcoord[i] = {tc.f[i * tc.nc], tc.f[i * tc.nc + 1]};
+                    has_tc = true;
+                }
+                int tid = -1;
+                material(prim.get("material"), mesh.material, tid);
+                mesh.diffuse_texture_id = has_tc ? tid : -1;
+                model->meshes.push_back(std::move(mesh));
+            }
+            return;                                                       // sutil does not descend below a mesh node
+        }
+        for (const Json& ch : list(node, "children").arr)
+            if (ch.kind == Json::Num && ch.num >= 0 && (size_t)ch.num < jnodes.arr.size()) visit(jnodes.arr[(size_t)ch.num], xf, depth + 1);
+    };
+    for (size_t i = 0; i < jnodes.arr.size(); i++)
+        if (is_root[i]) visit(jnodes.arr[i], m4_identity(), 0);
+    if (!failure.empty()) return bad(failure);
     *out = model.release();
     return FOVPT_OK;
 }

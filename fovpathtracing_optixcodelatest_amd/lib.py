@@ -19,7 +19,7 @@ EXPORTS = [
     "fovpt_probe_build_cdf", "fovpt_camera_uvw", "fovpt_debug_math", "fovpt_debug_buffer", "fovpt_debug_trace",
     "fovpt_gather_plan", "fovpt_gather_pack", "fovpt_gather_unpack",
     "fovpt_comm_get_unique_id", "fovpt_comm_init", "fovpt_comm_destroy", "fovpt_gather_frame",
-    "fovpt_model_load_obj", "fovpt_model_destroy", "fovpt_model_counts", "fovpt_model_get_mesh", "fovpt_model_get_texture",
+    "fovpt_model_load_obj", "fovpt_model_load_gltf", "fovpt_model_destroy", "fovpt_model_counts", "fovpt_model_get_mesh", "fovpt_model_get_texture",
     "fovpt_image_load_float4", "fovpt_image_free",
 ]
 
@@ -111,6 +111,7 @@ def load():
     L.fovpt_debug_buffer.argtypes = [vp, C.c_char_p, C.POINTER(vp), C.POINTER(sz)]
     L.fovpt_debug_trace.argtypes = [vp, i32, vp, vp, vp, vp, vp]
     L.fovpt_model_load_obj.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.fovpt_model_load_gltf.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.fovpt_model_destroy.argtypes = [vp]
     L.fovpt_model_destroy.restype = None
     L.fovpt_model_counts.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]

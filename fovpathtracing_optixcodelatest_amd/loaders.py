@@ -533,14 +533,20 @@ def load_obj(obj_file: str) -> Model:
     return model
 
 
-def load_obj_native(obj_file: str) -> Model:
+def load_gltf_native(gltf_file: str) -> Model:
+    """load_gltf through the library's host-side loader (fovpt_model_load_gltf, csrc/model_loader.cpp) -- what a C++ caller gets
+    from `loadGLTF` in include/Model.h."""
+    return load_obj_native(gltf_file, entry="fovpt_model_load_gltf")
+
+
+def load_obj_native(obj_file: str, entry: str = "fovpt_model_load_obj") -> Model:
     """The same model through the library's host-side loader (fovpt_model_load_obj, csrc/model_loader.cpp) -- what a C++
     caller gets from `loadOBJ` in include/Model.h.  Each mesh also carries `.normal` ((N,3) float32 or None)."""
     import ctypes as C
     from . import abi, lib
     L = lib.load()
     h = C.c_void_p()
-    lib.check(None, L.fovpt_model_load_obj(os.fsencode(obj_file), C.byref(h)))
+    lib.check(None, getattr(L, entry)(os.fsencode(obj_file), C.byref(h)))
     try:
         nm, nt = C.c_int(0), C.c_int(0)
         lib.check(None, L.fovpt_model_counts(h, C.byref(nm), C.byref(nt)))
@@ -747,6 +753,19 @@ def _m4(rows):
     return np.array(rows, np.float32).reshape(4, 4)
 
 
+def _matmul4(a, b):
+    """sutil::Matrix<4,4>::operator* (sutil/Matrix.h:339-355): sum = 0; sum += a[i][k] * b[k][j] for k = 0..3, in binary32 (no
+    BLAS, no fused multiply-add: the library's C++ loader states the same operations in the same order)."""
+    out = np.zeros((4, 4), np.float32)
+    for i in range(4):
+        for j in range(4):
+            acc = np.float32(0.0)
+            for k in range(4):
+                acc = np.float32(acc + np.float32(a[i, k] * b[k, j]))
+            out[i, j] = acc
+    return out
+
+
 def _quat_matrix(x, y, z, w):
     """sutil::Quaternion(w, x, y, z).rotationMatrix() (sutil/Quaternion.h:239-269): binary32, the quaternion
     is used as given (not normalised), same operation order."""
@@ -875,7 +894,7 @@ def load_gltf(gltf_file: str) -> Model:
         S = _m4([[s[0], 0, 0, 0], [0, s[1], 0, 0], [0, 0, s[2], 0], [0, 0, 0, 1]]) if s else np.eye(4, dtype=np.float32)
         mm = node.get("matrix")
         M = np.array(mm, np.float32).reshape(4, 4).T if mm else np.eye(4, dtype=np.float32)     # column-major in the file
-        xf = ((((parent @ M).astype(np.float32) @ T).astype(np.float32) @ R).astype(np.float32) @ S).astype(np.float32)
+        xf = _matmul4(_matmul4(_matmul4(_matmul4(parent, M), T), R), S)
         if "camera" in node:
             return
         if "mesh" in node:
@@ -883,7 +902,9 @@ def load_gltf(gltf_file: str) -> Model:
                 if prim.get("mode", 4) != 4:
                     continue
                 pos = accessor(prim["attributes"]["POSITION"]).astype(np.float32)
-                world = (pos @ xf[:3, :3].T + xf[:3, 3]).astype(np.float32)
+                # Matrix<4,4> * float4 with w = 1 (Matrix.h:467-485): ((m0 x + m1 y) + m2 z) + m3, element-wise binary32
+                x, y, z = pos[:, 0], pos[:, 1], pos[:, 2]
+                world = np.stack([((xf[i, 0] * x + xf[i, 1] * y) + xf[i, 2] * z) + xf[i, 3] for i in range(3)], 1).astype(np.float32)
                 if "indices" in prim:
                     idx = accessor(prim["indices"]).astype(np.uint32).reshape(-1)
                 else:

@@ -57,6 +57,17 @@ inline void addBox(Model* model, Material& mat, const float3& pos, const float3&
     model->meshes.push_back(mesh);
 }
 
+inline Model* modelFromHandle(fovpt_model* h);
+
+// glTF 2.0 (.gltf / .glb) -> Model with sutil::Scene's node rules (sutil/Scene.cpp:109-442), one mesh per triangle primitive in
+// world space: the library's host-side loader (fovpt_model_load_gltf), no tinygltf needed.  Throws std::runtime_error.
+inline Model* loadGLTF(const std::string& gltfFile)
+{
+    fovpt_model* h = nullptr;
+    if (fovpt_model_load_gltf(gltfFile.c_str(), &h) != FOVPT_OK) throw std::runtime_error(fovpt_last_error(nullptr));
+    return modelFromHandle(h);
+}
+
 // loadOBJ of Model.cpp:138-217 (declared Model.h:42): the scene as the reference's loader builds it -- one mesh per
 // (shape, material), per-shape vertex and texture maps, Kd -> color, Ke -> emission, textures as stbi_load gives them,
 // mirrored along y.  The work is done by the library's host-side loader (fovpt_model_load_obj, csrc/model_loader.cpp);
@@ -65,6 +76,12 @@ inline Model* loadOBJ(const std::string& objFile)
 {
     fovpt_model* h = nullptr;
     if (fovpt_model_load_obj(objFile.c_str(), &h) != FOVPT_OK) throw std::runtime_error(fovpt_last_error(nullptr));
+    return modelFromHandle(h);
+}
+
+// copies what the library's loader built into the reference's Model / TriangleMesh / Texture (Model.h:10-43) and frees the handle
+inline Model* modelFromHandle(fovpt_model* h)
+{
     int nm = 0, nt = 0;
     fovpt_model_counts(h, &nm, &nt);
     Model* model = new Model;

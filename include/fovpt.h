@@ -333,6 +333,12 @@ typedef struct fovpt_model_mesh {
     int32_t diffuse_texture_id;      /* index into the model's textures, or -1                 */
 } fovpt_model_mesh;
 int fovpt_model_load_obj(const char* obj_file, fovpt_model** out);
+/* glTF 2.0 (.gltf with external or data-URI buffers, or a .glb container) -> the same model structure, one mesh per triangle
+ * primitive in WORLD space, with the node rules of sutil::Scene (sutil/Scene.cpp:109-442: roots = nodes without a parent,
+ * parent * matrix * T * R * S in binary32, nothing below a mesh or camera node, base colour / roughness / metallic factors,
+ * emissiveFactor -> emission, base colour texture from a PNG / TGA / PPM file).  Replaces tinygltf + sutil::loadScene for C++
+ * callers; include/Model.h wraps it as `Model* loadGLTF(const std::string&)`.                                            */
+int fovpt_model_load_gltf(const char* gltf_file, fovpt_model** out);
 void fovpt_model_destroy(fovpt_model* model);
 int fovpt_model_counts(const fovpt_model* model, int* num_meshes, int* num_textures);
 int fovpt_model_get_mesh(const fovpt_model* model, int i, fovpt_model_mesh* out);

@@ -421,3 +421,147 @@ def test_oversized_image_headers_under_asan(tmp_path):
             assert "rc=0 meshes=1 textures=0" in out[n], out[n]        # a texture that cannot be read is id -1, Model.cpp:129-131
         else:
             assert "rc=0" not in out[n], out[n]
+
+
+def _same_model(a, b):
+    assert len(a.meshes) == len(b.meshes) and len(a.textures) == len(b.textures)
+    for x, y in zip(a.meshes, b.meshes):
+        assert np.array_equal(x.vertex.view(np.uint32), y.vertex.view(np.uint32)) and np.array_equal(x.index, y.index)
+        assert (x.texcoord is None) == (y.texcoord is None)
+        if x.texcoord is not None:
+            assert np.array_equal(x.texcoord.view(np.uint32), y.texcoord.view(np.uint32))
+        assert bytes(x.material) == bytes(y.material) and x.texture_id == y.texture_id
+    for x, y in zip(a.textures, b.textures):
+        assert np.array_equal(x, y)
+
+
+def test_gltf_through_the_library_loader_is_the_python_loader(tmp_path):
+    """fovpt_model_load_gltf (csrc/model_loader.cpp, what a C++ caller's loadGLTF uses) against loaders.load_gltf, bit for
+    bit: the fixture scene as .gltf (external + data-URI buffers) and as .glb, then seeded scenes with node hierarchies, every
+    component type, strided and normalised accessors, matrices and non-unit quaternions, and a PNG base colour texture."""
+    import json, struct, base64
+    from tests.common import encode_png
+    path, _ = _gltf_fixture(tmp_path)
+    _same_model(loaders.load_gltf_native(path), loaders.load_gltf(path))
+    g = json.load(open(path))
+    blob = (tmp_path / "geo.bin").read_bytes()
+    del g["buffers"][0]["uri"]
+    js = json.dumps(g).encode(); js += b" " * ((-len(js)) % 4)
+    bn = blob + b"\0" * ((-len(blob)) % 4)
+    (tmp_path / "s.glb").write_bytes(struct.pack("<4sII", b"glTF", 2, 12 + 8 + len(js) + 8 + len(bn)) + struct.pack("<II", len(js), 0x4E4F534A) + js
+                                     + struct.pack("<II", len(bn), 0x004E4942) + bn)
+    _same_model(loaders.load_gltf_native(str(tmp_path / "s.glb")), loaders.load_gltf(str(tmp_path / "s.glb")))
+    for seed in range(12):
+        rng = np.random.default_rng(seed)
+        d = tmp_path / ("g%d" % seed)
+        d.mkdir()
+        chunks, views, accs = [], [], []
+
+        def add(arr, ctype, typ, normalized=False, stride=0):
+            raw = np.ascontiguousarray(arr)
+            elem = raw.dtype.itemsize * (raw.shape[1] if raw.ndim > 1 else 1)
+            if stride:
+                buf = bytearray(stride * raw.shape[0])
+                for i in range(raw.shape[0]):
+                    buf[i * stride:i * stride + elem] = raw[i].tobytes()
+                data = bytes(buf)
+            else:
+                data = raw.tobytes()
+            off = sum(len(c) for c in chunks)
+            pad = (-len(data)) % 4
+            chunks.append(data + b"\0" * pad)
+            v = {"buffer": 0, "byteOffset": off, "byteLength": len(data)}
+            if stride:
+                v["byteStride"] = stride
+            views.append(v)
+            a = {"bufferView": len(views) - 1, "componentType": ctype, "count": int(raw.shape[0]), "type": typ}
+            if normalized:
+                a["normalized"] = True
+            accs.append(a)
+            return len(accs) - 1
+        meshes, mats = [], []
+        tex = rng.integers(0, 256, (5, 7, 4), dtype=np.uint8)
+        (d / "t.png").write_bytes(encode_png(tex, 8, 6))
+        for m in range(int(rng.integers(1, 4))):
+            prims = []
+            for _ in range(int(rng.integers(1, 3))):
+                nv = int(rng.integers(3, 20))
+                pos = add(rng.normal(0, 3, (nv, 3)).astype(np.float32), 5126, "VEC3", stride=int(rng.choice([0, 16, 20])))
+                attrs = {"POSITION": pos}
+                kind = int(rng.integers(0, 4))
+                if kind == 1:
+                    attrs["TEXCOORD_0"] = add(rng.random((nv, 2)).astype(np.float32), 5126, "VEC2")
+                elif kind == 2:
+                    attrs["TEXCOORD_0"] = add(rng.integers(0, 65536, (nv, 2)).astype(np.uint16), 5123, "VEC2", normalized=True)
+                elif kind == 3:
+                    attrs["TEXCOORD_0"] = add(rng.integers(0, 256, (nv, 2)).astype(np.uint8), 5121, "VEC2", normalized=True, stride=4)
+                p = {"attributes": attrs, "material": int(rng.integers(0, 3))}
+                it = int(rng.integers(0, 4))
+                ni = int(rng.integers(1, 9)) * 3 + int(rng.integers(0, 3))          # not always a multiple of three
+                if it == 1:
+                    p["indices"] = add(rng.integers(0, nv, ni).astype(np.uint8), 5121, "SCALAR")
+                elif it == 2:
+                    p["indices"] = add(rng.integers(0, nv, ni).astype(np.uint16), 5123, "SCALAR")
+                elif it == 3:
+                    p["indices"] = add(rng.integers(0, nv, ni).astype(np.uint32), 5125, "SCALAR")
+                if rng.random() < 0.15:
+                    p["mode"] = 1
+                prims.append(p)
+            meshes.append({"primitives": prims})
+        for k in range(3):
+            pbr = {}
+            if rng.random() < 0.7:
+                pbr["baseColorFactor"] = [float(x) for x in rng.random(4)]
+            if rng.random() < 0.5:
+                pbr["roughnessFactor"] = float(rng.random())
+            if rng.random() < 0.5:
+                pbr["metallicFactor"] = float(rng.random())
+            if k == 1:
+                pbr["baseColorTexture"] = {"index": 0}
+            mm = {"pbrMetallicRoughness": pbr} if pbr or rng.random() < 0.5 else {}
+            if rng.random() < 0.5:
+                mm["emissiveFactor"] = [float(x) for x in rng.random(3) * 4]
+            mats.append(mm)
+        nodes = []
+        nn = int(rng.integers(2, 9))
+        for i in range(nn):
+            n = {}
+            r = rng.random()
+            if r < 0.5:
+                n["mesh"] = int(rng.integers(0, len(meshes)))
+            if rng.random() < 0.5:
+                n["translation"] = [float(x) for x in rng.normal(0, 5, 3)]
+            if rng.random() < 0.5:
+                n["rotation"] = [float(x) for x in rng.normal(0, 1, 4)]            # not normalised, used as given
+            if rng.random() < 0.5:
+                n["scale"] = [float(x) for x in rng.uniform(0.2, 3, 3)]
+            if rng.random() < 0.3:
+                n["matrix"] = [float(x) for x in rng.normal(0, 1, 16)]
+            kids = [j for j in range(i + 1, nn) if rng.random() < 0.3]
+            if kids:
+                n["children"] = kids
+            nodes.append(n)
+        # every node has at most one parent (a tree, as glTF requires): keep only the first parent of a child
+        seen = set()
+        for n in nodes:
+            if "children" in n:
+                n["children"] = [c for c in n["children"] if not (c in seen or seen.add(c))]
+                if not n["children"]:
+                    del n["children"]
+        blob = b"".join(chunks)
+        use_uri = seed % 2 == 0
+        if use_uri:
+            (d / "b.bin").write_bytes(blob)
+        g = {"asset": {"version": "2.0"},
+             "buffers": [{"byteLength": len(blob), "uri": "b.bin" if use_uri else "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}],
+             "bufferViews": views, "accessors": accs, "meshes": meshes, "materials": mats, "nodes": nodes,
+             "images": [{"uri": "t.png"}], "textures": [{"source": 0}]}
+        (d / "s.gltf").write_text(json.dumps(g, indent=1 if seed % 3 == 0 else None))
+        _same_model(loaders.load_gltf_native(str(d / "s.gltf")), loaders.load_gltf(str(d / "s.gltf")))
+    # malformed input is an error with a message, not a crash
+    (tmp_path / "bad.gltf").write_text("{\"nodes\": [{\"mesh\": 3}], ")
+    with pytest.raises(Exception):
+        loaders.load_gltf_native(str(tmp_path / "bad.gltf"))
+    (tmp_path / "bad2.gltf").write_text(json.dumps({"nodes": [{"mesh": 3}], "meshes": []}))
+    with pytest.raises(Exception):
+        loaders.load_gltf_native(str(tmp_path / "bad2.gltf"))
