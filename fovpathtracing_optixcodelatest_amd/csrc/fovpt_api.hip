@@ -11,6 +11,9 @@
 #include <vector>
 
 #include "fovpt_device.h"
+#ifndef FOVPT_ASYNC_LAST_SHADE_DEFAULT
+#define FOVPT_ASYNC_LAST_SHADE_DEFAULT 0
+#endif
 #ifndef FOVPT_SPLIT_BUDGET_DEFAULT
 #define FOVPT_SPLIT_BUDGET_DEFAULT 0.0f
 #endif
@@ -54,6 +57,7 @@ struct StateSet {
     hipEvent_t ev_shade[FOVPT_MAX_ITERS + 1] = {};
     hipEvent_t ev_shadow[FOVPT_MAX_ITERS + 1] = {};
     hipEvent_t ev_done = nullptr;          // recorded after the resolve of the last job that used this set
+    hipEvent_t ev_last_closest = nullptr;  // completion of the job's last closest-hit launch (the last shading launch may run on the shadow stream)
     bool used = false;
     std::vector<DevBuf*> all()
     {
@@ -100,6 +104,7 @@ struct fovpt_ctx {
     StateSet set[2];
     unsigned jobs = 0;                     // jobs issued so far; job j uses set[j & 1]
     int grid = 2048, grid_shadow = 1024, grid_shade = 1024;
+    int async_last_shade = FOVPT_ASYNC_LAST_SHADE_DEFAULT;   // 1: the last shading launch of a job runs on the shadow stream (see run_job)
     uint64_t slot_budget = 64ull << 20;    // sample slots per wavefront job (~330 B of state and queues each, two sets)
     // stats
     fovpt_stats stats;
@@ -396,16 +401,26 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     // Every radiance cell has one writer, so the only joins are: shade(it+2) reuses the shadow queue
     // buffer of bounce it, and resolve needs everything -- it runs on the shadow stream, behind the last
     // occlusion launch (which waited for the last shade), so the main chain is free for the next job.
-    { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qa, sq[0], cap, cnt, 0, -1, grid); }
+    // The LAST shading launch of a job feeds nothing on the main chain (no closest-hit launch follows it): with
+    // async_last_shade it runs on the shadow stream, in front of the last occlusion launch and the resolve, so the main stream
+    // is free for the next job's generate and camera rays one shading launch earlier.
+    const bool tail_async = c->async_last_shade != 0;
+    { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qa, sq[0], cap, cnt, 0, -1, grid, (tail_async && iters == 1) ? S.ev_last_closest : nullptr); }
     const int nsq = iters < FOVPT_NSQ ? iters : FOVPT_NSQ;        // (only that many buffers are allocated)
     for (int it = 0; it < iters; it++) {
-        if (it >= nsq) HIPCHK(c, hipStreamWaitEvent(st, S.ev_shadow[it - nsq], 0));
-        // the events ride on the kernels' own completion signals (hipExtLaunchKernel): a separate
-        // hipEventRecord would put a marker packet between shade(it) and closest(it+1), ~6 us on the critical path
-        { Timed t(c, 2); fovpt_launch_shade(st, fd, sc, ps, qa, qb, sq[it % nsq], cap, cnt, it, c->grid_shade, S.ev_shade[it]); }
-        HIPCHK(c, hipStreamWaitEvent(ss, S.ev_shade[it], 0));
+        const bool last = it + 1 == iters;
+        if (last && tail_async) {
+            HIPCHK(c, hipStreamWaitEvent(ss, S.ev_last_closest, 0));      // (the shadow queue it writes was read by occlusion(it - nsq): earlier on this stream)
+            { Timed t(c, 2, ss); fovpt_launch_shade(ss, fd, sc, ps, qa, qb, sq[it % nsq], cap, cnt, it, c->grid_shade); }
+        } else {
+            if (it >= nsq) HIPCHK(c, hipStreamWaitEvent(st, S.ev_shadow[it - nsq], 0));
+            // the events ride on the kernels' own completion signals (hipExtLaunchKernel): a separate
+            // hipEventRecord would put a marker packet between shade(it) and closest(it+1), ~6 us on the critical path
+            { Timed t(c, 2); fovpt_launch_shade(st, fd, sc, ps, qa, qb, sq[it % nsq], cap, cnt, it, c->grid_shade, S.ev_shade[it]); }
+            HIPCHK(c, hipStreamWaitEvent(ss, S.ev_shade[it], 0));
+        }
         { Timed t(c, 3, ss); fovpt_launch_traverse(ss, sc, ps, qb, sq[it % nsq], cap, cnt, -1, it, c->grid_shadow, S.ev_shadow[it]); }
-        if (it + 1 < iters) { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qb, sq[0], cap, cnt, it + 1, -1, grid); }
+        if (!last) { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qb, sq[0], cap, cnt, it + 1, -1, grid, (tail_async && it + 2 == iters) ? S.ev_last_closest : nullptr); }
         const RayQueue tmp = qa; qa = qb; qb = tmp;
     }
     { Timed t(c, 4, ss); fovpt_launch_resolve(ss, fd, ps, cnt, S.ev_done); }
@@ -510,6 +525,7 @@ int fovpt_create(fovpt_ctx** out, int device)
     c->grid_shade = c->grid;
     if (const char* g = getenv("FOVPT_GRID_SHADE")) { const int v = atoi(g); if (v > 0 && v <= 16) c->grid_shade = c->num_cus * v; }     // tuning: blocks per CU
     c->grid_shade = (c->grid_shade + FOVPT_SHARDS - 1) / FOVPT_SHARDS * FOVPT_SHARDS;
+    if (const char* a = getenv("FOVPT_ASYNC_LAST_SHADE")) c->async_last_shade = atoi(a) != 0;
     if (const char* sb = getenv("FOVPT_SLOT_BUDGET")) { const long long v = atoll(sb); if (v > 0) c->slot_budget = (uint64_t)v; }   // tests: force chunking
     // the main chain is the critical path: give it the higher priority so occlusion waves only fill gaps
     int prio_lo = 0, prio_hi = 0;
@@ -522,6 +538,7 @@ int fovpt_create(fovpt_ctx** out, int device)
             if (e == hipSuccess) e = hipEventCreateWithFlags(&S.ev_shadow[k], hipEventDefault);
         }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&S.ev_done, hipEventDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&S.ev_last_closest, hipEventDefault);
     }
     if (e != hipSuccess) { fovpt_destroy(c); return fail(nullptr, FOVPT_E_DEVICE, "stream/event creation: %s", hipGetErrorString(e)); }
     *out = c;
@@ -542,6 +559,7 @@ void fovpt_destroy(fovpt_ctx* c)
             if (S.ev_shadow[k]) (void)hipEventDestroy(S.ev_shadow[k]);
         }
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
+        if (S.ev_last_closest) (void)hipEventDestroy(S.ev_last_closest);
         for (DevBuf* b : S.all()) b->release();
     }
     (void)fovpt_comm_destroy(c);

@@ -504,6 +504,520 @@ bool decode_tga(const std::vector<uint8_t>& d, Image& img)
     return true;
 }
 
+// JPEG (JFIF / Adobe; baseline, extended sequential and progressive DCT; 8 bits; 1, 3 or 4 components) -> rgba8 as
+// stbi_load(..., 4) of the vendored stb_image gives it -- the JPEG format leaves the inverse DCT, the chroma interpolation and
+// the colour conversion to the decoder, so "like stb_image" means ITS choices, restated here:
+//   * coefficients: Huffman + EXTEND as the standard says (T.81 F.2.2, G.1.2 for the progressive refinements), dequantised in
+//     16-bit arithmetic ((short)(value * q)); a baseline block as it is decoded, a progressive one when all scans are in;
+//   * inverse DCT: the "slow integer" transform of the IJG library in the scaling stb_image uses (12-bit constants, columns
+//     rounded to 2 extra bits, rows to the sample, +128, clamped);
+//   * chroma: replicated horizontally for factors other than 2; for 2 the triangle filters 3:1 (one axis) and 9:3:3:1 (both)
+//     centred between the samples, edge samples repeated; the luma rows a chroma row pair serves are chosen as stb does;
+//   * Y Cb Cr -> R G B in 20.12 fixed point with the constants 1.40200, 0.71414, 0.34414 (its product masked to 16 bits),
+//     1.77200; a three-component image is taken as RGB when its component ids are 'R' 'G' 'B' or when an Adobe marker says
+//     "no transform" and there is no JFIF marker; four components are CMYK (transform 0) or YCCK (2), combined with K by the
+//     8 x 8 -> 8 multiply of the graphics literature ((t + (t >> 8)) >> 8, t = a b + 128).
+// Held against the reference's own stb_image through oracle/_ref (tests/golden/ref_jpeg.npz).
+struct JpegDecoder {
+    struct Huff { uint8_t size[257]; uint16_t code[256]; uint8_t value[256]; uint32_t maxcode[18]; int delta[17]; uint8_t fast[512]; bool ok = false; };
+    struct Comp {
+        int id = 0, h = 1, v = 1, tq = 0, hd = 0, ha = 0, pred = 0;
+        int x = 0, y = 0, w2 = 0, h2 = 0, bw = 0;               // valid samples, padded plane size, blocks per row
+        std::vector<uint8_t> plane;
+        std::vector<short> coeff;                                 // progressive only: 64 per block
+    };
+    const uint8_t* d; size_t n, pos = 0;
+    Huff hdc[4], hac[4];
+    uint16_t q[4][64];
+    Comp comp[4];
+    int ncomp = 0, width = 0, height = 0, hmax = 1, vmax = 1, mcux = 0, mcuy = 0;
+    bool progressive = false, jfif = false;
+    int adobe = -1, rgb_ids = 0, restart = 0;
+    int scan_n = 0, order[4] = {0, 0, 0, 0}, ss = 0, se = 63, ah = 0, al = 0, eobrun = 0, todo = 0;
+    uint32_t bits = 0; int nbits = 0; int marker = 0xff; bool nomore = false;
+
+    static const uint8_t* zigzag()
+    {
+        static const uint8_t z[64 + 15] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34, 27, 20, 13, 6, 7, 14, 21, 28, 35,
+                                           42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63,
+                                           63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63, 63};
+        return z;
+    }
+    int get8() { return pos < n ? d[pos++] : 0; }
+    int get16() { const int a = get8(); return (a << 8) | get8(); }
+    void skip(int k) { pos = k < 0 ? n : std::min(n, pos + (size_t)k); }
+
+    bool build(Huff& h, const int* count)
+    {
+        int k = 0;
+        for (int i = 0; i < 16; i++) for (int j = 0; j < count[i]; j++) { if (k >= 256) return false; h.size[k++] = (uint8_t)(i + 1); }
+        h.size[k] = 0;
+        unsigned code = 0;
+        int kk = 0;
+        for (int j = 1; j <= 16; j++) {
+            h.delta[j] = kk - (int)code;
+            if (h.size[kk] == j) {
+                while (h.size[kk] == j) h.code[kk++] = (uint16_t)(code++);
+                if (code - 1 >= (1u << j)) return false;
+            }
+            h.maxcode[j] = code << (16 - j);
+            code <<= 1;
+        }
+        h.maxcode[17] = 0xffffffffu;
+        memset(h.fast, 255, sizeof(h.fast));
+        for (int i = 0; i < k; i++) {
+            const int sz = h.size[i];
+            if (sz <= 9) { const int c = h.code[i] << (9 - sz), m = 1 << (9 - sz); for (int j = 0; j < m; j++) h.fast[c + j] = (uint8_t)i; }
+        }
+        h.ok = true;
+        return true;
+    }
+    // the entropy-coded segment: bytes until a marker; 0xff 0x00 is a data byte 0xff; after a marker (or the end of the file) zeros
+    void fill()
+    {
+        do {
+            const unsigned b = nomore ? 0u : (unsigned)get8();
+            if (b == 0xff) {
+                int c = get8();
+                while (c == 0xff) c = get8();
+                if (c != 0) { marker = c; nomore = true; return; }
+            }
+            bits |= b << (24 - nbits);
+            nbits += 8;
+        } while (nbits <= 24);
+    }
+    int decode(const Huff& h)
+    {
+        if (nbits < 16) fill();
+        const int c = (int)(bits >> 23) & 511;
+        int k = h.fast[c];
+        if (k < 255) {
+            const int sz = h.size[k];
+            if (sz > nbits) return -1;
+            bits <<= sz; nbits -= sz;
+            return h.value[k];
+        }
+        const unsigned t = bits >> 16;
+        for (k = 10; ; k++) if (t < h.maxcode[k]) break;
+        if (k == 17) { nbits -= 16; return -1; }
+        if (k > nbits) return -1;
+        const int idx = (int)((bits >> (32 - k)) & ((1u << k) - 1u)) + h.delta[k];
+        if (idx < 0 || idx > 255) return -1;
+        nbits -= k; bits <<= k;
+        return h.value[idx];
+    }
+    int getbits(int k)
+    {
+        if (k <= 0 || k > 16) return 0;
+        if (nbits < k) fill();
+        const unsigned r = bits >> (32 - k);
+        bits <<= k; nbits -= k;
+        return (int)r;
+    }
+    int getbit() { if (nbits < 1) fill(); const unsigned r = bits >> 31; bits <<= 1; nbits--; return (int)r; }
+    int extend(int k)                                             // RECEIVE + EXTEND (T.81 F.2.2.1)
+    {
+        if (k <= 0 || k > 16) return 0;
+        const int v = getbits(k);
+        return v < (1 << (k - 1)) ? v - (1 << k) + 1 : v;
+    }
+    void reset()
+    {
+        nbits = 0; bits = 0; nomore = false; marker = 0xff; eobrun = 0;
+        for (int i = 0; i < 4; i++) comp[i].pred = 0;
+        todo = restart ? restart : 0x7fffffff;
+    }
+
+    static int fix(float x) { return (int)(x * 4096 + 0.5); }
+    static uint8_t clamp8(int x) { return (unsigned)x > 255u ? (x < 0 ? 0 : 255) : (uint8_t)x; }
+    // one 1-D pass of the transform on s[0..7] (stride st): even part into x0..x3, odd part into t0..t3
+    static void idct1(const int* s, int st, int& x0, int& x1, int& x2, int& x3, int& t0, int& t1, int& t2, int& t3)
+    {
+        int p2 = s[2 * st], p3 = s[6 * st];
+        int p1 = (p2 + p3) * fix(0.5411961f);
+        t2 = p1 + p3 * fix(-1.847759065f);
+        t3 = p1 + p2 * fix(0.765366865f);
+        p2 = s[0]; p3 = s[4 * st];
+        t0 = (p2 + p3) * 4096; t1 = (p2 - p3) * 4096;
+        x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;
+        t0 = s[7 * st]; t1 = s[5 * st]; t2 = s[3 * st]; t3 = s[1 * st];
+        p3 = t0 + t2; int p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;
+        const int p5 = (p3 + p4) * fix(1.175875602f);
+        t0 = t0 * fix(0.298631336f); t1 = t1 * fix(2.053119869f); t2 = t2 * fix(3.072711026f); t3 = t3 * fix(1.501321110f);
+        p1 = p5 + p1 * fix(-0.899976223f); p2 = p5 + p2 * fix(-2.562915447f); p3 = p3 * fix(-1.961570560f); p4 = p4 * fix(-0.390180644f);
+        t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
+    }
+    static void idct(uint8_t* out, int stride, const short* data)
+    {
+        int in[64], val[64];
+        for (int i = 0; i < 64; i++) in[i] = data[i];
+        for (int i = 0; i < 8; i++) {
+            const int* c = in + i; int* v = val + i;
+            if (!c[8] && !c[16] && !c[24] && !c[32] && !c[40] && !c[48] && !c[56]) { const int dc = c[0] * 4; for (int k = 0; k < 8; k++) v[8 * k] = dc; continue; }
+            int x0, x1, x2, x3, t0, t1, t2, t3;
+            idct1(c, 8, x0, x1, x2, x3, t0, t1, t2, t3);
+            x0 += 512; x1 += 512; x2 += 512; x3 += 512;
+            v[0] = (x0 + t3) >> 10; v[56] = (x0 - t3) >> 10; v[8] = (x1 + t2) >> 10; v[48] = (x1 - t2) >> 10;
+            v[16] = (x2 + t1) >> 10; v[40] = (x2 - t1) >> 10; v[24] = (x3 + t0) >> 10; v[32] = (x3 - t0) >> 10;
+        }
+        for (int i = 0; i < 8; i++) {
+            int x0, x1, x2, x3, t0, t1, t2, t3;
+            idct1(val + 8 * i, 1, x0, x1, x2, x3, t0, t1, t2, t3);
+            const int bias = 65536 + (128 << 17);
+            x0 += bias; x1 += bias; x2 += bias; x3 += bias;
+            uint8_t* o = out + (size_t)i * stride;
+            o[0] = clamp8((x0 + t3) >> 17); o[7] = clamp8((x0 - t3) >> 17); o[1] = clamp8((x1 + t2) >> 17); o[6] = clamp8((x1 - t2) >> 17);
+            o[2] = clamp8((x2 + t1) >> 17); o[5] = clamp8((x2 - t1) >> 17); o[3] = clamp8((x3 + t0) >> 17); o[4] = clamp8((x3 - t0) >> 17);
+        }
+    }
+
+    bool block_baseline(short* data, Comp& C)
+    {
+        const Huff &dc = hdc[C.hd], &ac = hac[C.ha];
+        if (!dc.ok || !ac.ok) return false;
+        const int t = decode(dc);
+        if (t < 0 || t > 15) return false;
+        memset(data, 0, 64 * sizeof(short));
+        C.pred += t ? extend(t) : 0;
+        data[0] = (short)(C.pred * q[C.tq][0]);
+        int k = 1;
+        do {
+            const int rs = decode(ac);
+            if (rs < 0) return false;
+            const int sz = rs & 15, r = rs >> 4;
+            if (sz == 0) { if (rs != 0xf0) break; k += 16; }
+            else { k += r; const int zz = zigzag()[k++]; data[zz] = (short)(extend(sz) * q[C.tq][zz]); }
+        } while (k < 64);
+        return true;
+    }
+    bool block_prog_dc(short* data, Comp& C)
+    {
+        if (se != 0) return false;
+        if (ah == 0) {
+            if (!hdc[C.hd].ok) return false;
+            memset(data, 0, 64 * sizeof(short));
+            const int t = decode(hdc[C.hd]);
+            if (t < 0 || t > 15) return false;
+            C.pred += t ? extend(t) : 0;
+            data[0] = (short)(C.pred << al);
+        } else if (getbit()) data[0] += (short)(1 << al);
+        return true;
+    }
+    bool block_prog_ac(short* data, Comp& C)
+    {
+        if (ss == 0 || !hac[C.ha].ok) return false;
+        const Huff& ac = hac[C.ha];
+        if (ah == 0) {
+            if (eobrun) { eobrun--; return true; }
+            int k = ss;
+            do {
+                const int rs = decode(ac);
+                if (rs < 0) return false;
+                const int sz = rs & 15, r = rs >> 4;
+                if (sz == 0) {
+                    if (r < 15) { eobrun = (1 << r); if (r) eobrun += getbits(r); eobrun--; break; }
+                    k += 16;
+                } else { k += r; const int zz = zigzag()[k++]; data[zz] = (short)(extend(sz) << al); }
+            } while (k <= se);
+        } else {
+            const short bit = (short)(1 << al);
+            auto refine = [&](short* p) { if (getbit() && (*p & bit) == 0) { if (*p > 0) *p += bit; else *p -= bit; } };
+            if (eobrun) {
+                eobrun--;
+                for (int k = ss; k <= se; k++) { short* p = &data[zigzag()[k]]; if (*p != 0) refine(p); }
+            } else {
+                int k = ss;
+                do {
+                    const int rs = decode(ac);
+                    if (rs < 0) return false;
+                    int sz = rs & 15, r = rs >> 4;
+                    if (sz == 0) {
+                        if (r < 15) { eobrun = (1 << r) - 1; if (r) eobrun += getbits(r); r = 64; }
+                    } else {
+                        if (sz != 1) return false;
+                        sz = getbit() ? bit : -bit;
+                    }
+                    while (k <= se) {
+                        short* p = &data[zigzag()[k++]];
+                        if (*p != 0) refine(p);
+                        else { if (r == 0) { *p = (short)sz; break; } r--; }
+                    }
+                } while (k <= se);
+            }
+        }
+        return true;
+    }
+    // the blocks of one scan; false = corrupt.  (A missing restart marker ends the scan early and keeps what there is.)
+    bool scan()
+    {
+        reset();
+        short tmp[64];
+        auto one = [&](Comp& C, int bx, int by) -> bool {
+            if (!progressive) {
+                if (!block_baseline(tmp, C)) return false;
+                idct(C.plane.data() + (size_t)C.w2 * by * 8 + (size_t)bx * 8, C.w2, tmp);
+                return true;
+            }
+            short* data = C.coeff.data() + 64 * ((size_t)bx + (size_t)by * C.bw);
+            return ss == 0 ? block_prog_dc(data, C) : block_prog_ac(data, C);
+        };
+        auto counted = [&]() -> int {                            // 0 go on, 1 the scan ends here
+            if (--todo <= 0) {
+                if (nbits < 24) fill();
+                if (!(marker >= 0xd0 && marker <= 0xd7)) return 1;
+                reset();
+            }
+            return 0;
+        };
+        if (scan_n == 1) {
+            Comp& C = comp[order[0]];
+            const int w = (C.x + 7) >> 3, h = (C.y + 7) >> 3;
+            for (int j = 0; j < h; j++)
+                for (int i = 0; i < w; i++) { if (!one(C, i, j)) return false; if (counted()) return true; }
+            return true;
+        }
+        if (progressive && ss != 0) return false;                // an interleaved scan carries DC coefficients only
+        for (int j = 0; j < mcuy; j++)
+            for (int i = 0; i < mcux; i++) {
+                for (int k = 0; k < scan_n; k++) {
+                    Comp& C = comp[order[k]];
+                    for (int y = 0; y < C.v; y++)
+                        for (int x = 0; x < C.h; x++) if (!one(C, i * C.h + x, j * C.v + y)) return false;
+                }
+                if (counted()) return true;
+            }
+        return true;
+    }
+    int next_marker()
+    {
+        if (marker != 0xff) { const int m = marker; marker = 0xff; return m; }
+        int x = get8();
+        if (x != 0xff) return 0xff;
+        while (x == 0xff) x = get8();
+        return x;
+    }
+    bool segment(int m)                                           // DRI, DQT, DHT, APPn, COM
+    {
+        if (m == 0xff) return false;
+        if (m == 0xdd) { if (get16() != 4) return false; restart = get16(); return true; }
+        if (m == 0xdb) {
+            int L = get16() - 2;
+            while (L > 0) {
+                const int b = get8(), p = b >> 4, t = b & 15;
+                if ((p != 0 && p != 1) || t > 3) return false;
+                for (int i = 0; i < 64; i++) q[t][zigzag()[i]] = (uint16_t)(p ? get16() : get8());
+                L -= p ? 129 : 65;
+            }
+            return L == 0;
+        }
+        if (m == 0xc4) {
+            int L = get16() - 2;
+            while (L > 0) {
+                int sizes[16], cnt = 0;
+                const int b = get8(), tc = b >> 4, th = b & 15;
+                if (tc > 1 || th > 3) return false;
+                for (int i = 0; i < 16; i++) { sizes[i] = get8(); cnt += sizes[i]; }
+                if (cnt > 256) return false;
+                L -= 17;
+                Huff& h = tc == 0 ? hdc[th] : hac[th];
+                if (!build(h, sizes)) return false;
+                for (int i = 0; i < cnt; i++) h.value[i] = (uint8_t)get8();
+                L -= cnt;
+            }
+            return L == 0;
+        }
+        if ((m >= 0xe0 && m <= 0xef) || m == 0xfe) {
+            int L = get16();
+            if (L < 2) return false;
+            L -= 2;
+            if (m == 0xe0 && L >= 5) {
+                static const uint8_t tag[5] = {'J', 'F', 'I', 'F', 0};
+                bool ok = true;
+                for (int i = 0; i < 5; i++) if (get8() != tag[i]) ok = false;
+                L -= 5;
+                if (ok) jfif = true;
+            } else if (m == 0xee && L >= 12) {
+                static const uint8_t tag[6] = {'A', 'd', 'o', 'b', 'e', 0};
+                bool ok = true;
+                for (int i = 0; i < 6; i++) if (get8() != tag[i]) ok = false;
+                L -= 6;
+                if (ok) { get8(); get16(); get16(); adobe = get8(); L -= 6; }
+            }
+            skip(L);
+            return true;
+        }
+        return false;
+    }
+    bool frame_header()
+    {
+        const int Lf = get16();
+        if (Lf < 11 || get8() != 8) return false;
+        height = get16(); width = get16();
+        if (height == 0 || width == 0 || height > (1 << 24) || width > (1 << 24)) return false;
+        ncomp = get8();
+        if (ncomp != 3 && ncomp != 1 && ncomp != 4) return false;
+        if (Lf != 8 + 3 * ncomp) return false;
+        rgb_ids = 0;
+        for (int i = 0; i < ncomp; i++) {
+            static const uint8_t rgb[3] = {'R', 'G', 'B'};
+            comp[i].id = get8();
+            if (ncomp == 3 && comp[i].id == rgb[i]) rgb_ids++;
+            const int b = get8();
+            comp[i].h = b >> 4; comp[i].v = b & 15; comp[i].tq = get8();
+            if (!comp[i].h || comp[i].h > 4 || !comp[i].v || comp[i].v > 4 || comp[i].tq > 3) return false;
+        }
+        if ((uint64_t)width * (uint64_t)height > (1ull << 28)) return false;
+        hmax = vmax = 1;
+        for (int i = 0; i < ncomp; i++) { hmax = std::max(hmax, comp[i].h); vmax = std::max(vmax, comp[i].v); }
+        mcux = (width + hmax * 8 - 1) / (hmax * 8); mcuy = (height + vmax * 8 - 1) / (vmax * 8);
+        for (int i = 0; i < ncomp; i++) {
+            Comp& C = comp[i];
+            C.x = (width * C.h + hmax - 1) / hmax; C.y = (height * C.v + vmax - 1) / vmax;
+            C.w2 = mcux * C.h * 8; C.h2 = mcuy * C.v * 8; C.bw = C.w2 / 8;
+            C.plane.assign((size_t)C.w2 * C.h2, 0);
+            if (progressive) C.coeff.assign((size_t)C.w2 * C.h2, 0);
+        }
+        return true;
+    }
+    bool scan_header()
+    {
+        const int Ls = get16();
+        scan_n = get8();
+        if (scan_n < 1 || scan_n > 4 || scan_n > ncomp || Ls != 6 + 2 * scan_n) return false;
+        for (int i = 0; i < scan_n; i++) {
+            const int id = get8(), b = get8();
+            int which = 0;
+            while (which < ncomp && comp[which].id != id) which++;
+            if (which == ncomp) return false;
+            comp[which].hd = b >> 4; comp[which].ha = b & 15;
+            if (comp[which].hd > 3 || comp[which].ha > 3) return false;
+            order[i] = which;
+        }
+        ss = get8(); se = get8();
+        const int a = get8();
+        ah = a >> 4; al = a & 15;
+        if (progressive) { if (ss > 63 || se > 63 || ss > se || ah > 13 || al > 13) return false; }
+        else { if (ss != 0 || ah != 0 || al != 0) return false; se = 63; }
+        return true;
+    }
+    bool planes()                                                 // header, all scans, and for a progressive file the final transform
+    {
+        if (next_marker() != 0xd8) return false;
+        int m = next_marker();
+        while (!(m == 0xc0 || m == 0xc1 || m == 0xc2)) {
+            if (!segment(m)) return false;
+            m = next_marker();
+            while (m == 0xff) { if (pos >= n) return false; m = next_marker(); }
+        }
+        progressive = m == 0xc2;
+        if (!frame_header()) return false;
+        m = next_marker();
+        while (m != 0xd9) {
+            if (m == 0xda) {
+                if (!scan_header() || !scan()) return false;
+                if (marker == 0xff) { while (pos < n) { if (get8() == 255) { marker = get8(); break; } } }     // padding behind the scan data
+            } else if (m == 0xdc) { if (get16() != 4 || get16() != height) return false; }
+            else if (!segment(m)) return false;
+            m = next_marker();
+        }
+        if (progressive)
+            for (int c = 0; c < ncomp; c++) {
+                Comp& C = comp[c];
+                const int w = (C.x + 7) >> 3, h = (C.y + 7) >> 3;
+                for (int j = 0; j < h; j++)
+                    for (int i = 0; i < w; i++) {
+                        short* data = C.coeff.data() + 64 * ((size_t)i + (size_t)j * C.bw);
+                        for (int k = 0; k < 64; k++) data[k] = (short)(data[k] * q[C.tq][k]);
+                        idct(C.plane.data() + (size_t)C.w2 * j * 8 + (size_t)i * 8, C.w2, data);
+                    }
+            }
+        return true;
+    }
+    static uint8_t mul8(uint8_t a, uint8_t b) { const unsigned t = (unsigned)a * b + 128u; return (uint8_t)((t + (t >> 8)) >> 8); }
+    bool image(Image& img)
+    {
+        if (!planes()) return false;
+        const bool is_rgb = ncomp == 3 && (rgb_ids == 3 || (adobe == 0 && !jfif));
+        img.w = width; img.h = height;
+        img.px.assign((size_t)width * height, 0);
+        struct Up { int hs, vs, ystep, wl, ypos; const uint8_t *l0, *l1; std::vector<uint8_t> buf; };
+        Up up[4];
+        for (int k = 0; k < ncomp; k++) {
+            Up& r = up[k];
+            r.hs = hmax / comp[k].h; r.vs = vmax / comp[k].v; r.ystep = r.vs >> 1; r.wl = (width + r.hs - 1) / r.hs; r.ypos = 0;
+            r.l0 = r.l1 = comp[k].plane.data();
+            r.buf.assign((size_t)width + 3 + 8, 0);
+        }
+        const uint8_t* row[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int j = 0; j < height; j++) {
+            for (int k = 0; k < ncomp; k++) {
+                Up& r = up[k];
+                const bool bot = r.ystep >= (r.vs >> 1);
+                const uint8_t *a = bot ? r.l1 : r.l0, *b = bot ? r.l0 : r.l1;     // near, far
+                uint8_t* o = r.buf.data();
+                const int w = r.wl;
+                if (r.hs == 1 && r.vs == 1) row[k] = a;
+                else {
+                    if (r.hs == 1 && r.vs == 2) for (int i = 0; i < w; i++) o[i] = (uint8_t)((3 * a[i] + b[i] + 2) >> 2);
+                    else if (r.hs == 2 && r.vs == 1) {
+                        if (w == 1) o[0] = o[1] = a[0];
+                        else {
+                            o[0] = a[0]; o[1] = (uint8_t)((a[0] * 3 + a[1] + 2) >> 2);
+                            int i;
+                            for (i = 1; i < w - 1; i++) { const int t = 3 * a[i] + 2; o[i * 2] = (uint8_t)((t + a[i - 1]) >> 2); o[i * 2 + 1] = (uint8_t)((t + a[i + 1]) >> 2); }
+                            o[i * 2] = (uint8_t)((a[w - 2] * 3 + a[w - 1] + 2) >> 2); o[i * 2 + 1] = a[w - 1];
+                        }
+                    } else if (r.hs == 2 && r.vs == 2) {
+                        if (w == 1) o[0] = o[1] = (uint8_t)((3 * a[0] + b[0] + 2) >> 2);
+                        else {
+                            int t1 = 3 * a[0] + b[0];
+                            o[0] = (uint8_t)((t1 + 2) >> 2);
+                            for (int i = 1; i < w; i++) {
+                                const int t0 = t1;
+                                t1 = 3 * a[i] + b[i];
+                                o[i * 2 - 1] = (uint8_t)((3 * t0 + t1 + 8) >> 4); o[i * 2] = (uint8_t)((3 * t1 + t0 + 8) >> 4);
+                            }
+                            o[w * 2 - 1] = (uint8_t)((t1 + 2) >> 2);
+                        }
+                    } else {
+                        r.buf.resize(std::max(r.buf.size(), (size_t)w * r.hs + 8)); o = r.buf.data();
+                        for (int i = 0; i < w; i++) for (int s2 = 0; s2 < r.hs; s2++) o[i * r.hs + s2] = a[i];
+                    }
+                    row[k] = o;
+                }
+                if (++r.ystep >= r.vs) { r.ystep = 0; r.l0 = r.l1; if (++r.ypos < comp[k].y) r.l1 += comp[k].w2; }
+            }
+            uint32_t* out = img.px.data() + (size_t)j * width;
+            auto ycc = [&](int i, int& R, int& G, int& B) {
+                const int yf = (row[0][i] << 20) + (1 << 19), cr = row[2][i] - 128, cb = row[1][i] - 128;
+                const int c1 = ((int)(1.40200f * 4096.0f + 0.5f)) << 8, c2 = ((int)(0.71414f * 4096.0f + 0.5f)) << 8;
+                const int c3 = ((int)(0.34414f * 4096.0f + 0.5f)) << 8, c4 = ((int)(1.77200f * 4096.0f + 0.5f)) << 8;
+                R = (yf + cr * c1) >> 20;
+                G = (int)((unsigned)yf + (unsigned)(cr * -c2) + ((unsigned)(cb * -c3) & 0xffff0000u)) >> 20;
+                B = (yf + cb * c4) >> 20;
+                R = clamp8(R); G = clamp8(G); B = clamp8(B);
+            };
+            for (int i = 0; i < width; i++) {
+                int R, G, B;
+                if (ncomp == 1) R = G = B = row[0][i];
+                else if (ncomp == 3) { if (is_rgb) { R = row[0][i]; G = row[1][i]; B = row[2][i]; } else ycc(i, R, G, B); }
+                else if (adobe == 0) { const uint8_t kk = row[3][i]; R = mul8(row[0][i], kk); G = mul8(row[1][i], kk); B = mul8(row[2][i], kk); }
+                else if (adobe == 2) { const uint8_t kk = row[3][i]; ycc(i, R, G, B); R = mul8((uint8_t)(255 - R), kk); G = mul8((uint8_t)(255 - G), kk); B = mul8((uint8_t)(255 - B), kk); }
+                else ycc(i, R, G, B);
+                out[i] = (uint32_t)R | ((uint32_t)G << 8) | ((uint32_t)B << 16) | 0xff000000u;
+            }
+        }
+        return true;
+    }
+};
+
+bool decode_jpeg(const std::vector<uint8_t>& d, Image& img)
+{
+    JpegDecoder J{d.data(), d.size()};
+    memset(J.q, 0, sizeof(J.q));
+    return J.image(img);
+}
+
 bool ends_with_ci(const std::string& s, const char* suffix)
 {
     const size_t n = strlen(suffix);
@@ -518,6 +1032,7 @@ bool load_texture_file(const std::string& path, Image& img)
     if (!read_file(path, d)) return false;
     bool ok = false;
     if (d.size() >= 8 && d[0] == 0x89 && d[1] == 'P') ok = decode_png(d, img);
+    else if (d.size() >= 3 && d[0] == 0xff && d[1] == 0xd8 && d[2] == 0xff) ok = decode_jpeg(d, img);
     else if (d.size() >= 2 && d[0] == 'P' && d[1] == '6') ok = decode_ppm(d, img);
     else if (ends_with_ci(path, ".tga")) ok = decode_tga(d, img);
     if (!ok) return false;
@@ -1177,6 +1692,7 @@ static int image_load_float4_impl(const char* file, int* width, int* height, fov
         Image img;
         bool ok = false;
         if (d.size() >= 8 && d[0] == 0x89 && d[1] == 'P') ok = decode_png(d, img);
+        else if (d.size() >= 3 && d[0] == 0xff && d[1] == 0xd8 && d[2] == 0xff) ok = decode_jpeg(d, img);
         else if (d.size() >= 2 && d[0] == 'P' && d[1] == '6') ok = decode_ppm(d, img);
         else if (ends_with_ci(file, ".tga")) ok = decode_tga(d, img);
         if (!ok) { fovpt_internal_set_error((std::string(file) + ": not an image this loader reads (.hdr, .png, .tga, binary .ppm)").c_str()); return FOVPT_E_INVALID; }
@@ -1194,6 +1710,28 @@ static int image_load_float4_impl(const char* file, int* width, int* height, fov
     *width = w; *height = h; *texels = out;
     return FOVPT_OK;
 }
+
+// stbi_load(file, &w, &h, &n, STBI_rgb_alpha) for the formats this library reads (PNG, JPEG, TGA, binary PPM): rgba8, row 0 first
+// (NOT mirrored: loadTexture does that itself, Model.cpp:117-126).  *pixels is malloc'ed; release it with fovpt_image_free_rgba8.
+int fovpt_image_load_rgba8(const char* file, int* width, int* height, uint32_t** pixels)
+{
+    if (pixels) *pixels = nullptr;
+    return guarded("fovpt_image_load_rgba8", [&]() -> int {
+        if (!file || !width || !height || !pixels) { fovpt_internal_set_error("fovpt_image_load_rgba8: null argument"); return FOVPT_E_INVALID; }
+        Image img;
+        if (!load_texture_file(file, img)) {
+            fovpt_internal_set_error((std::string(file) + ": cannot open, or not an image this loader reads (.png, .jpg, .tga, binary .ppm)").c_str());
+            return FOVPT_E_INVALID;
+        }
+        uint32_t* out = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)img.w * img.h);
+        if (!out) { fovpt_internal_set_error("fovpt_image_load_rgba8: out of memory"); return FOVPT_E_NOMEM; }
+        for (int y = 0; y < img.h; y++)                              // load_texture_file mirrors along y: undo it
+            memcpy(out + (size_t)y * img.w, img.px.data() + (size_t)(img.h - 1 - y) * img.w, sizeof(uint32_t) * (size_t)img.w);
+        *width = img.w; *height = img.h; *pixels = out;
+        return FOVPT_OK;
+    });
+}
+void fovpt_image_free_rgba8(uint32_t* pixels) { free(pixels); }
 
 void fovpt_image_free(fovpt_float4* texels) { free(texels); }
 

@@ -20,7 +20,7 @@ EXPORTS = [
     "fovpt_gather_plan", "fovpt_gather_pack", "fovpt_gather_unpack",
     "fovpt_comm_get_unique_id", "fovpt_comm_init", "fovpt_comm_destroy", "fovpt_gather_frame",
     "fovpt_model_load_obj", "fovpt_model_load_gltf", "fovpt_model_destroy", "fovpt_model_counts", "fovpt_model_get_mesh", "fovpt_model_get_texture",
-    "fovpt_image_load_float4", "fovpt_image_free",
+    "fovpt_image_load_float4", "fovpt_image_free", "fovpt_image_load_rgba8", "fovpt_image_free_rgba8",
 ]
 
 
@@ -120,8 +120,11 @@ def load():
     L.fovpt_image_load_float4.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(vp)]
     L.fovpt_image_free.argtypes = [vp]
     L.fovpt_image_free.restype = None
+    L.fovpt_image_load_rgba8.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(vp)]
+    L.fovpt_image_free_rgba8.argtypes = [vp]
+    L.fovpt_image_free_rgba8.restype = None
     for name in EXPORTS:
-        if name not in ("fovpt_destroy", "fovpt_last_error", "fovpt_stream", "fovpt_model_destroy", "fovpt_image_free"):
+        if name not in ("fovpt_destroy", "fovpt_last_error", "fovpt_stream", "fovpt_model_destroy", "fovpt_image_free", "fovpt_image_free_rgba8"):
             getattr(L, name).restype = i32
     _lib = L
     return L

@@ -292,10 +292,25 @@ def _decode_ppm(data: bytes) -> np.ndarray:
     return np.concatenate([rgb, np.full((h, w, 1), 255, np.uint8)], axis=2)
 
 
+def decode_jpeg_native(path: str) -> np.ndarray:
+    """(H, W, 4) uint8 as stbi_load(path, ..., 4) returns it, through the library's host-side decoder (no GPU needed)."""
+    import ctypes as C
+    from . import lib
+    L = lib.load()
+    w, h, px = C.c_int32(0), C.c_int32(0), C.c_void_p()
+    lib.check(None, L.fovpt_image_load_rgba8(os.fsencode(path), C.byref(w), C.byref(h), C.byref(px)))
+    try:
+        words = np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_uint32)), (h.value, w.value)).copy()
+    finally:
+        L.fovpt_image_free_rgba8(px)
+    return np.stack([(words >> s) & 255 for s in (0, 8, 16, 24)], -1).astype(np.uint8)
+
+
 def _load_texture(path: str) -> Optional[np.ndarray]:
     """RGBA8 as (H, W) uint32, mirrored along y (Model.cpp:117-126).  PNG, TGA and binary PPM are decoded
-    here; JPEG and the rarer formats stb_image knows go through Pillow when it is installed, otherwise
-    they count as "could not load" (texture id -1, Model.cpp:129-131)."""
+    here; JPEG by the library's host-side decoder (fovpt_image_load_rgba8: stb_image's inverse DCT, chroma
+    interpolation and colour conversion, bit for bit -- Pillow's libjpeg would give other pixels); anything
+    else counts as "could not load" (texture id -1, Model.cpp:129-131)."""
     if not os.path.exists(path):
         return None
     try:
@@ -307,9 +322,10 @@ def _load_texture(path: str) -> Optional[np.ndarray]:
             rgba = _decode_ppm(data)
         elif path.lower().endswith(".tga"):
             rgba = decode_tga(data)
+        elif data[:3] == b"\xff\xd8\xff":
+            rgba = decode_jpeg_native(path)
         else:
-            from PIL import Image                          # optional dependency
-            rgba = np.asarray(Image.open(path).convert("RGBA"), np.uint8)
+            return None
     except Exception:
         return None
     rgba = rgba[::-1]                                       # mirror along y

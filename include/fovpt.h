@@ -318,7 +318,7 @@ int fovpt_camera_uvw(const fovpt_float3* eye, const fovpt_float3* lookat, const 
 /* ---- Scene ingestion on the host: what loadOBJ returns, PT_sv5_/Model.cpp:138-217 --------------------
  * (with addVertex :49-82 and loadTexture :84-136, i.e. the vendored tinyobjloader with triangulate = true and
  * stbi_load(..., STBI_rgb_alpha) mirrored along y).  Plain host code, no GPU needed.  One mesh per (shape, material id);
- * PNG, Truevision TGA and binary PPM textures are decoded, any other format (JPEG, ...) counts as "could not load"
+ * PNG, JPEG, Truevision TGA and binary PPM textures are decoded, any other format counts as "could not load"
  * (texture id -1, as :129-131).
  * The arrays stay owned by the model; include/Model.h wraps this as `Model* loadOBJ(const std::string&)`.
  * Errors: FOVPT_E_INVALID, text from fovpt_last_error(NULL) ("Could not read OBJ model from ...", :160-162).          */
@@ -350,6 +350,11 @@ int fovpt_model_get_texture(const fovpt_model* model, int i, const uint32_t** pi
  * fovpt_image_free.  Errors: FOVPT_E_INVALID with fovpt_last_error(NULL) (the reference does not check stbi_loadf's
  * result and would build the CDF over a null pointer).                                                               */
 int fovpt_image_load_float4(const char* file, int* width, int* height, fovpt_float4** texels);
+/* stbi_load(file, &w, &h, &n, STBI_rgb_alpha) as loadTexture calls it (PT_sv5_/Model.cpp:106-107) for the formats this library
+ * reads -- PNG, JPEG (baseline, extended, progressive; gray, YCbCr, RGB, CMYK, YCCK), Truevision TGA, binary PPM: rgba8, row 0
+ * first, bit for bit what the reference's vendored stb_image returns.  *pixels is malloc'ed: fovpt_image_free_rgba8.           */
+int fovpt_image_load_rgba8(const char* file, int* width, int* height, uint32_t** pixels);
+void fovpt_image_free_rgba8(uint32_t* pixels);
 void fovpt_image_free(fovpt_float4* texels);
 
 /* ---- device self-test hook (tests only): evaluates one scalar function on the GPU
