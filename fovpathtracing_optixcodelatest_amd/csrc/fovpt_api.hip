@@ -103,7 +103,7 @@ struct fovpt_ctx {
     // rays and its resolve, on the shadow stream) runs beside the head of job k+1 (generate, camera rays)
     StateSet set[2];
     unsigned jobs = 0;                     // jobs issued so far; job j uses set[j & 1]
-    int grid = 2048, grid_shadow = 1024, grid_shade = 1024;
+    int grid = 2048, grid_trace = 2048, grid_shadow = 1024, grid_shade = 1024;
     int async_last_shade = FOVPT_ASYNC_LAST_SHADE_DEFAULT;   // 1: the last shading launch of a job runs on the shadow stream (see run_job)
     uint64_t slot_budget = 64ull << 20;    // sample slots per wavefront job (~330 B of state and queues each, two sets)
     // stats
@@ -405,7 +405,7 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     // async_last_shade it runs on the shadow stream, in front of the last occlusion launch and the resolve, so the main stream
     // is free for the next job's generate and camera rays one shading launch earlier.
     const bool tail_async = c->async_last_shade != 0;
-    { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qa, sq[0], cap, cnt, 0, -1, grid, (tail_async && iters == 1) ? S.ev_last_closest : nullptr); }
+    { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qa, sq[0], cap, cnt, 0, -1, c->grid_trace, (tail_async && iters == 1) ? S.ev_last_closest : nullptr); }
     const int nsq = iters < FOVPT_NSQ ? iters : FOVPT_NSQ;        // (only that many buffers are allocated)
     for (int it = 0; it < iters; it++) {
         const bool last = it + 1 == iters;
@@ -420,7 +420,7 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
             HIPCHK(c, hipStreamWaitEvent(ss, S.ev_shade[it], 0));
         }
         { Timed t(c, 3, ss); fovpt_launch_traverse(ss, sc, ps, qb, sq[it % nsq], cap, cnt, -1, it, c->grid_shadow, S.ev_shadow[it]); }
-        if (!last) { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qb, sq[0], cap, cnt, it + 1, -1, grid, (tail_async && it + 2 == iters) ? S.ev_last_closest : nullptr); }
+        if (!last) { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qb, sq[0], cap, cnt, it + 1, -1, c->grid_trace, (tail_async && it + 2 == iters) ? S.ev_last_closest : nullptr); }
         const RayQueue tmp = qa; qa = qb; qb = tmp;
     }
     { Timed t(c, 4, ss); fovpt_launch_resolve(ss, fd, ps, cnt, S.ev_done); }
@@ -514,15 +514,18 @@ int fovpt_create(fovpt_ctx** out, int device)
     memset(&c->stats, 0, sizeof(c->stats));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
-    c->grid = c->num_cus * 8;                 // 8 blocks of 256 = 32 waves per CU, grid-stride over the queues; a multiple of FOVPT_SHARDS
-    c->grid_shadow = c->num_cus * 6;          // occlusion launches (measured best of 2..8 with per-wave ray pools)
-    if (const char* g = getenv("FOVPT_GRID")) { const int v = atoi(g); if (v > 0 && v <= 64) c->grid = c->num_cus * v; }                 // tuning: blocks per CU
+    c->grid = c->num_cus * 8;                 // generate: 8 blocks of 256 = 32 waves per CU, grid-stride; a multiple of FOVPT_SHARDS
+    c->grid_trace = c->num_cus * FOVPT_GRID_PER_CU;   // closest-hit launches, in units of 256 threads (k_traverse's own blocks are FOVPT_TBLOCK threads)
+    c->grid_shadow = c->num_cus * FOVPT_GRID_SHADOW_PER_CU;   // occlusion launches (measured best of 2..8 with per-wave ray pools)
+    if (const char* g = getenv("FOVPT_GRID_GEN")) { const int v = atoi(g); if (v > 0 && v <= 64) c->grid = c->num_cus * v; }             // tuning: blocks per CU
+    if (const char* g = getenv("FOVPT_GRID")) { const int v = atoi(g); if (v > 0 && v <= 64) c->grid_trace = c->num_cus * v; }           // tuning: blocks per CU
     if (const char* g = getenv("FOVPT_GRID_SHADOW")) { const int v = atoi(g); if (v > 0 && v <= 16) c->grid_shadow = c->num_cus * v; }   // tuning: blocks per CU
     c->grid = (c->grid + FOVPT_SHARDS - 1) / FOVPT_SHARDS * FOVPT_SHARDS;      // shard_capacity() relies on it
+    c->grid_trace = (c->grid_trace + FOVPT_SHARDS - 1) / FOVPT_SHARDS * FOVPT_SHARDS;
     c->grid_shadow = (c->grid_shadow + FOVPT_SHARDS - 1) / FOVPT_SHARDS * FOVPT_SHARDS;      // the work fetch of k_traverse relies on equal shard groups
     // the shading kernel holds 4 waves per SIMD (104 VGPRs) = 4 blocks per CU; twice the resident number of blocks is
     // measured best (blocks per CU 2 / 3 / 4 / 6 / 8: shading 0.307 / 0.274 / 0.261 / 0.263 / 0.244 ms per C3 frame)
-    c->grid_shade = c->grid;
+    c->grid_shade = c->num_cus * 8;
     if (const char* g = getenv("FOVPT_GRID_SHADE")) { const int v = atoi(g); if (v > 0 && v <= 16) c->grid_shade = c->num_cus * v; }     // tuning: blocks per CU
     c->grid_shade = (c->grid_shade + FOVPT_SHARDS - 1) / FOVPT_SHARDS * FOVPT_SHARDS;
     if (const char* a = getenv("FOVPT_ASYNC_LAST_SHADE")) c->async_last_shade = atoi(a) != 0;
@@ -1233,7 +1236,7 @@ int fovpt_debug_trace(fovpt_ctx* c, int n, const float* origins3, const float* d
     sc.meshes = (const MeshDev*)c->meshes.p; sc.textures = (const TexDev*)c->textures.p;
     sc.num_tris = c->num_tris; sc.any_catcher = c->any_catcher;
     sc.tri_off = (uint32_t)((const char*)c->tris - (const char*)c->nodes);
-    fovpt_launch_traverse(st, sc, ps, q, sq, cap, cnt, 0, -1, c->grid);              // closest hit, as run_job launches it
+    fovpt_launch_traverse(st, sc, ps, q, sq, cap, cnt, 0, -1, c->grid_trace);        // closest hit, as run_job launches it
     fovpt_launch_traverse(st, sc, ps, q, sq, cap, cnt, -1, 0, c->grid_shadow);       // occlusion, as run_job launches it
     HIPCHK(c, hipGetLastError());
     std::vector<float> hit((size_t)n * 4), cell((size_t)n * 4 * (size_t)c->cfg.max_depth);

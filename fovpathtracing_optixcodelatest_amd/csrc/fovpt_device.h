@@ -21,9 +21,19 @@
 #define FOVPT_STACK 64            // traversal stack entries per ray, all in LDS (a wide node leaves <= 3 behind)
 #define FOVPT_QUADS_PER_BLOCK (FOVPT_BLOCK / 4)
 #ifndef FOVPT_TBLOCK
-#define FOVPT_TBLOCK 256          // threads per block of k_traverse (256 or 1024: the rays of a block share one LDS stack array)
+#define FOVPT_TBLOCK 64           // threads per block of k_traverse (64, 256 or 1024: the rays of a block share one LDS stack array).
+                                  // 64 = a workgroup is ONE wave: it gives its slot, registers and 4.3 KB of LDS back the moment it ends (a
+                                  // 256-thread block holds all four slots until its slowest wave is through), and with more workgroups than
+                                  // slots the hardware's dispatcher is the run-time scheduler that atomics were too slow to be (EXPERIMENTS.md)
 #endif
 #define FOVPT_TQUADS (FOVPT_TBLOCK / 4)
+#ifndef FOVPT_GRID_PER_CU
+#define FOVPT_GRID_PER_CU 24        // closest-hit launches: 256-thread units per CU (8 = every wave slot once; 24 = three times as many
+                                    // one-wave workgroups as slots, measured best of 8 / 16 / 24 / 32 / 64)
+#endif
+#ifndef FOVPT_GRID_SHADOW_PER_CU
+#define FOVPT_GRID_SHADOW_PER_CU 6
+#endif
 #define FOVPT_MAX_PASSES 3
 #define FOVPT_MAX_ITERS 63         // wavefront iterations per frame (max_depth + catcher pass-throughs)
 #define FOVPT_SHARDS 8            // queue shards: one append counter per blockIdx % 8 (~ per XCD)
@@ -173,7 +183,7 @@ struct Counters {       // device-resident, zeroed per frame except the stats bl
     // diagnostics of a -DFOVPT_V_CYCLES=1 build (tools/stepcycles.py): s_memtime ticks (shader cycles) summed per wave
     unsigned long long cyc[2][8][16];   // [ray kind][iteration & 7][field], fields: see struct Cyc in wavefront.hip
     uint32_t hist[2][8][3][64];         // [kind][iteration & 7][node load wait /16 | node step /32 | leaf step /32][bin]
-    unsigned long long wtime[8][8192][2];   // [kind * 4 + iteration & 3][wave]: s_memrealtime (100 MHz) at the wave's start and end
+    unsigned long long wtime[8][32768][2];   // [kind * 4 + iteration & 3][wave]: s_memrealtime (100 MHz) at the wave's start and end
 #endif
 };
 static_assert(2 * (FOVPT_MAX_ITERS + 1) <= FOVPT_SHARD_STRIDE, "shard block holds both queues' sizes");

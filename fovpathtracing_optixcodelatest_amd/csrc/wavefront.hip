@@ -677,9 +677,9 @@ __device__ inline uint32_t quad_rot2(uint32_t v) { return (uint32_t)__builtin_am
 __device__ inline uint32_t quad_rot3(uint32_t v) { return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x93, 0xf, 0xf, true); }   // [3,0,1,2]
 
 enum { ROWB = FOVPT_TQUADS * 4,                 // byte distance of two stack rows
-       ROWSHIFT = FOVPT_TQUADS == 64 ? 8 : 10 };
+       ROWSHIFT = FOVPT_TQUADS == 16 ? 6 : FOVPT_TQUADS == 64 ? 8 : 10 };
 static_assert(FOVPT_LEAF_MAX <= 4, "a leaf is tested in one quad step");
-static_assert(FOVPT_TQUADS == 64 || FOVPT_TQUADS == 256, "row stride of the stack is 256 or 1024 bytes");
+static_assert(FOVPT_TQUADS == 16 || FOVPT_TQUADS == 64 || FOVPT_TQUADS == 256, "row stride of the stack is 64, 256 or 1024 bytes");
 
 // The traversal stack lives in LDS and is addressed through pointers that SAY so (address space 3, 32 bits): every access is a
 // ds_read / ds_write by construction.  With a generic `char*` that held only as long as the compiler could infer the address
@@ -1053,7 +1053,7 @@ __global__ __launch_bounds__(FOVPT_TBLOCK, FOVPT_V_WAVES) void k_traverse(SceneV
         const unsigned long long real1 = __builtin_amdgcn_s_memrealtime();
         const int kind = it_shadow >= 0 ? 1 : 0, itn = (it_shadow >= 0 ? it_shadow : it_closest) & 3;
         const uint32_t wave = blockIdx.x * (FOVPT_TBLOCK / 64) + (threadIdx.x >> 6);
-        if ((threadIdx.x & 63u) == 0u && wave < 8192u) { cnt->wtime[kind * 4 + itn][wave][0] = real0; cnt->wtime[kind * 4 + itn][wave][1] = real1; }
+        if ((threadIdx.x & 63u) == 0u && wave < 32768u) { cnt->wtime[kind * 4 + itn][wave][0] = real0; cnt->wtime[kind * 4 + itn][wave][1] = real1; }
         if (C.on) {
             unsigned long long* g = cnt->cyc[kind][itn];
             const uint32_t v[9] = {C.n_node, C.gap, C.load, C.alu, C.lds, C.n_leaf, C.lgap, C.lload, C.lrest};
@@ -1576,31 +1576,60 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_plan_owner(const FrameDev fd, u
     __syncthreads();
     if ((int)threadIdx.x < fd.world) block_count[(size_t)blockIdx.x * fd.world + threadIdx.x] = s_cnt[threadIdx.x];
 }
-// exclusive scan of the block counts, rank by rank (one thread per rank; built once per plan, not per frame)
-__global__ void k_plan_scan(uint32_t nblocks, int world, uint32_t* __restrict__ block_count, uint32_t* __restrict__ total)
+// exclusive scan of the block counts, rank by rank: ONE BLOCK per rank, every thread scans a contiguous chunk of the counts,
+// the chunk totals are scanned in LDS, the chunks are written back with their offsets.  (The plan is rebuilt whenever the gaze
+// moves -- every frame with an eye tracker -- so this is not a one-off: a single thread per rank walking 8-18 k blocks was.)
+__global__ __launch_bounds__(1024) void k_plan_scan(uint32_t nblocks, int world, uint32_t* __restrict__ block_count, uint32_t* __restrict__ total)
 {
-    const int r = (int)threadIdx.x;
+    __shared__ uint32_t s_part[1024];
+    const int r = (int)blockIdx.x;
     if (r >= world) return;
-    uint32_t run = 0u;
-    for (uint32_t b = 0; b < nblocks; b++) {
+    const uint32_t per = (nblocks + blockDim.x - 1u) / blockDim.x;
+    const uint32_t b0 = min(nblocks, threadIdx.x * per), b1 = min(nblocks, b0 + per);
+    uint32_t sum = 0u;
+    for (uint32_t b = b0; b < b1; b++) sum += block_count[(size_t)b * world + r];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t off = 1u; off < blockDim.x; off <<= 1) {                    // inclusive Hillis-Steele scan of the chunk totals
+        const uint32_t v = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = s_part[threadIdx.x] - sum;                                   // exclusive offset of my chunk
+    for (uint32_t b = b0; b < b1; b++) {
         const uint32_t c = block_count[(size_t)b * world + r];
         block_count[(size_t)b * world + r] = run;
         run += c;
     }
-    total[r] = run;
+    if (threadIdx.x == blockDim.x - 1u) total[r] = s_part[threadIdx.x];
 }
 // idx[rank_base[o] + block offset + position among the block's pixels of the same owner] = pixel
 __global__ __launch_bounds__(FOVPT_BLOCK) void k_plan_fill(uint32_t npix, int world, const uint8_t* __restrict__ owner, const uint32_t* __restrict__ block_off,
                                                           const uint32_t* __restrict__ rank_base, uint32_t* __restrict__ idx)
 {
-    __shared__ uint8_t s_owner[FOVPT_BLOCK];
-    const uint32_t i = blockIdx.x * FOVPT_BLOCK + threadIdx.x;
+    // position of a pixel among the block's pixels of the same owner, in ascending pixel order: within a wave one ballot per
+    // DISTINCT owner present (64 consecutive pixels span a handful of 8-pixel-wide tiles), the waves' counts meet in LDS.
+    // (Was: every thread scanning the up to 255 owners before it.)
+    __shared__ uint32_t s_cnt[FOVPT_BLOCK / 64][64];
+    const uint32_t i = blockIdx.x * FOVPT_BLOCK + threadIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t o = i < npix ? owner[i] : FOVPT_PLAN_NOBODY;
-    s_owner[threadIdx.x] = (uint8_t)o;
+    for (uint32_t k = threadIdx.x; k < (FOVPT_BLOCK / 64) * 64; k += FOVPT_BLOCK) (&s_cnt[0][0])[k] = 0u;
+    __syncthreads();
+    uint32_t in_wave = 0u;
+    unsigned long long todo = __ballot(o != FOVPT_PLAN_NOBODY);
+    while (todo) {                                                             // wave-uniform loop over the owners present
+        const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)o, (int)leader);
+        const unsigned long long same = __ballot(o == lo);
+        if (o == lo) in_wave = (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        if (lane == leader) s_cnt[wave][lo] = (uint32_t)__popcll(same);
+        todo &= ~same;
+    }
     __syncthreads();
     if (o == FOVPT_PLAN_NOBODY) return;
-    uint32_t before = 0u;
-    for (uint32_t t = 0; t < threadIdx.x; t++) before += s_owner[t] == o ? 1u : 0u;
+    uint32_t before = in_wave;
+    for (uint32_t w = 0; w < wave; w++) before += s_cnt[w][o];
     idx[rank_base[o] + block_off[(size_t)blockIdx.x * world + o] + before] = i;
 }
 __global__ void k_gather_pack(uint32_t n, const uint32_t* __restrict__ idx, const uint32_t* __restrict__ frame, uint32_t* __restrict__ packed)
@@ -1643,47 +1672,98 @@ __global__ void k_probe_records(size_t n, const float* __restrict__ cdfX, const 
 
 // ---- ProbeData::BuildCDF on the device (Probe.h:29-77) -----------------------------------------
 // fp32 sums are not associative and the reference accumulates strictly left to right, so the
-// parallelism is across rows only: one thread walks one row in order; a single thread then walks
-// the row totals.  Same bits as the host helper fovpt_probe_build_cdf.
-__global__ void k_cdf_rows(int w, int h, const float4* __restrict__ data, float* __restrict__ pdfX, float* __restrict__ cdfX,
-                           float* __restrict__ row_total)
+// parallelism is across rows only: one thread sums one row in order (out of LDS tiles that the
+// wave loaded coalesced); a single thread then walks the row totals.  Same bits as the host helper
+// fovpt_probe_build_cdf.
+#define CDF_ROWS 8          // rows per block: a 2048-row probe gives 256 blocks, one per CU
+#define CDF_COLS 256        // columns per tile = threads per block
+#define CDF_LD (CDF_COLS + 4)   // row pitch in LDS: 16-byte reads of CDF_ROWS different rows fall into different banks
+__global__ __launch_bounds__(CDF_COLS) void k_cdf_rows(int w, int h, const float4* __restrict__ data, float* __restrict__ pdfX, float* __restrict__ cdfX,
+                                                      float* __restrict__ row_total)
 {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= h) return;
-    float totalWeightX = 0.0f;
-    for (int i = 0; i < w; ++i) {
-        const float4 c = data[(size_t)j * w + i];
-        const float weight = c.x * 0.3f + c.y * 0.6f + c.z * 0.1f;          // Luminance, maths.h:165-168
-        totalWeightX += weight;
-        pdfX[(size_t)j * w + i] = weight;
-        cdfX[(size_t)j * w + i] = totalWeightX;
+    // A block = CDF_ROWS rows, walked in tiles of CDF_COLS columns.  All four waves read the tile's texels COALESCED (a wave
+    // = 64 consecutive texels of one row, 1 KB) and park their luminances in LDS; lane r of wave 0 then adds up row r's
+    // CDF_COLS values in order -- the fp32 sum of a row stays strictly left to right, which is what fixes its bits
+    // (Probe.h:41-51) -- and all waves write weights and running sums back out, coalesced.  The next tile's texels are in
+    // flight while the sums run.  (Was: one thread per row reading its row with a stride of w texels, every load a cache line
+    // of its own, 32 waves on the whole chip: 1.8 ms for a 4096 x 2048 probe.)
+    __shared__ __attribute__((aligned(16))) float s_w[CDF_ROWS][CDF_LD], s_c[CDF_ROWS][CDF_LD];
+    const int j0 = blockIdx.x * CDF_ROWS, t = threadIdx.x;
+    float run = 0.0f;                                                           // totalWeightX of row j0 + t so far (t < CDF_ROWS)
+    float4 c[CDF_ROWS];
+#pragma unroll
+    for (int r = 0; r < CDF_ROWS; r++) c[r] = (j0 + r < h && t < w) ? data[(size_t)(j0 + r) * w + t] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i0 = 0; i0 < w; i0 += CDF_COLS) {
+#pragma unroll
+        for (int r = 0; r < CDF_ROWS; r++) s_w[r][t] = c[r].x * 0.3f + c[r].y * 0.6f + c[r].z * 0.1f;      // Luminance, maths.h:165-168
+        __syncthreads();
+        const int in = i0 + CDF_COLS + t;
+#pragma unroll
+        for (int r = 0; r < CDF_ROWS; r++) c[r] = (j0 + r < h && in < w) ? data[(size_t)(j0 + r) * w + in] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t < CDF_ROWS && j0 + t < h) {
+            const int n = min(CDF_COLS, w - i0);
+            int k = 0;
+            for (; k + 4 <= n; k += 4) {
+                const float4 v = *(const float4*)&s_w[t][k];
+                float4 o;
+                run += v.x; o.x = run; run += v.y; o.y = run; run += v.z; o.z = run; run += v.w; o.w = run;
+                *(float4*)&s_c[t][k] = o;
+            }
+            for (; k < n; k++) { run += s_w[t][k]; s_c[t][k] = run; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < CDF_ROWS; r++) {
+            const int j = j0 + r, i = i0 + t;
+            if (j < h && i < w) { pdfX[(size_t)j * w + i] = s_w[r][t]; cdfX[(size_t)j * w + i] = s_c[r][t]; }
+        }
+        __syncthreads();
     }
-    const float invTotalWeightX = 1.0f / totalWeightX;
-    for (int i = 0; i < w; ++i) {
-        pdfX[(size_t)j * w + i] *= invTotalWeightX;
-        cdfX[(size_t)j * w + i] *= invTotalWeightX;
-    }
-    row_total[j] = totalWeightX;
+    if (t < CDF_ROWS && j0 + t < h) row_total[j0 + t] = run;
+}
+// second pass: pdf and cdf of every row times 1 / its total (the reference multiplies by the reciprocal, Probe.h:49-55)
+__global__ void k_cdf_rows_scale(int w, int h, float* __restrict__ pdfX, float* __restrict__ cdfX, const float* __restrict__ row_total)
+{
+    const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= (size_t)w * h) return;
+    const float invTotalWeightX = 1.0f / row_total[k / (size_t)w];
+    pdfX[k] *= invTotalWeightX;
+    cdfX[k] *= invTotalWeightX;
 }
 // (the running sum over the rows is sequential by contract -- one thread; the two divisions per row are not)
-__global__ void k_cdf_cols(int h, const float* __restrict__ row_total, float* __restrict__ pdfY, float* __restrict__ cdfY)
+__global__ __launch_bounds__(256) void k_cdf_cols(int h, const float* __restrict__ row_total, float* __restrict__ pdfY, float* __restrict__ cdfY)
 {
+    // chunks of the row totals go through LDS: the block loads a chunk, thread 0 adds it up in order, the block writes the
+    // running sums out.  (The one sequential thread used to read and write global memory value by value: 60 ns per row.)
+    __shared__ __attribute__((aligned(16))) float s_v[2048], s_c[2048];
     __shared__ float s_total;
     if (blockIdx.x != 0) return;
-    if (threadIdx.x == 0) {
-        float totalWeightY = 0.0f;
-        for (int j = 0; j < h; ++j) {
-            totalWeightY += row_total[j];
-            pdfY[j] = row_total[j];
-            cdfY[j] = totalWeightY;
+    float totalWeightY = 0.0f;                                                  // thread 0's
+    for (int j0 = 0; j0 < h; j0 += 2048) {
+        const int n = min(2048, h - j0);
+        for (int k = (int)threadIdx.x; k < n; k += (int)blockDim.x) s_v[k] = row_total[j0 + k];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int k = 0;
+            for (; k + 4 <= n; k += 4) {
+                const float4 v = *(const float4*)&s_v[k];
+                float4 o;
+                totalWeightY += v.x; o.x = totalWeightY; totalWeightY += v.y; o.y = totalWeightY;
+                totalWeightY += v.z; o.z = totalWeightY; totalWeightY += v.w; o.w = totalWeightY;
+                *(float4*)&s_c[k] = o;
+            }
+            for (; k < n; k++) { totalWeightY += s_v[k]; s_c[k] = totalWeightY; }
         }
-        s_total = totalWeightY;
+        __syncthreads();
+        for (int k = (int)threadIdx.x; k < n; k += (int)blockDim.x) { pdfY[j0 + k] = s_v[k]; cdfY[j0 + k] = s_c[k]; }
+        __syncthreads();
     }
+    if (threadIdx.x == 0) s_total = totalWeightY;
     __syncthreads();
-    const float totalWeightY = s_total;
-    for (int j = (int)threadIdx.x; j < h; j += (int)blockDim.x) {
-        cdfY[j] /= totalWeightY;
-        pdfY[j] /= totalWeightY;
+    const float total = s_total;
+    for (int j = (int)threadIdx.x; j < h; j += (int)blockDim.x) {              // divisions here, not reciprocals (Probe.h:68-72)
+        cdfY[j] /= total;
+        pdfY[j] /= total;
     }
 }
 
@@ -1720,7 +1800,13 @@ void fovpt_launch_traverse(hipStream_t st, SceneView sc, PathState ps, RayQueue 
 {
     // `done` rides on the kernel's own completion signal (no separate marker packet in the queue)
     // (`grid` counts blocks of 256 threads, as for the other kernels; the traversal block may be larger)
-    const int blocks = grid * FOVPT_BLOCK / FOVPT_TBLOCK > 0 ? grid * FOVPT_BLOCK / FOVPT_TBLOCK : 1;
+    int blocks = grid * FOVPT_BLOCK / FOVPT_TBLOCK > 0 ? grid * FOVPT_BLOCK / FOVPT_TBLOCK : 1;
+    if (it_shadow < 0) {
+        // a closest-hit launch reads at most 8 * cap rays (the shards' capacities): no more workgroups than it can have rounds of
+        // FOVPT_TQUADS rays (what matters for the small frames of a 1/N shard)
+        const unsigned long long rounds = (8ull * cap + FOVPT_TQUADS - 1) / FOVPT_TQUADS;
+        if ((unsigned long long)blocks > rounds) blocks = (int)((rounds + FOVPT_SHARDS - 1) / FOVPT_SHARDS * FOVPT_SHARDS);
+    }
     if (done) hipExtLaunchKernelGGL(k_traverse, dim3(blocks), dim3(FOVPT_TBLOCK), 0, st, nullptr, done, 0, sc, ps, queue, sq, cap, cnt, it_closest, it_shadow);
     else hipLaunchKernelGGL(k_traverse, dim3(blocks), dim3(FOVPT_TBLOCK), 0, st, sc, ps, queue, sq, cap, cnt, it_closest, it_shadow);
 }
@@ -1748,7 +1834,7 @@ void fovpt_launch_plan_owner(hipStream_t st, const FrameDev& fd, uint8_t* owner,
 void fovpt_launch_plan_scan_fill(hipStream_t st, uint32_t npix, uint32_t nblocks, int world, const uint8_t* owner, uint32_t* block_count,
                                  uint32_t* total, const uint32_t* rank_base, uint32_t* idx, int phase)
 {
-    if (phase == 0) hipLaunchKernelGGL(k_plan_scan, dim3(1), dim3(64), 0, st, nblocks, world, block_count, total);
+    if (phase == 0) hipLaunchKernelGGL(k_plan_scan, dim3(world), dim3(1024), 0, st, nblocks, world, block_count, total);
     else hipLaunchKernelGGL(k_plan_fill, dim3(nblocks), dim3(FOVPT_BLOCK), 0, st, npix, world, owner, block_count, rank_base, idx);
 }
 void fovpt_launch_gather_pack(hipStream_t st, uint32_t n, const uint32_t* idx, const uint32_t* frame, uint32_t* packed)
@@ -1771,7 +1857,8 @@ void fovpt_launch_probe_records(hipStream_t st, size_t n, const float* cdfX, con
 }
 void fovpt_launch_build_cdf(hipStream_t st, int w, int h, const float4* data, float* pdfX, float* cdfX, float* pdfY, float* cdfY, float* row_total)
 {
-    hipLaunchKernelGGL(k_cdf_rows, dim3((h + 63) / 64), dim3(64), 0, st, w, h, data, pdfX, cdfX, row_total);
+    hipLaunchKernelGGL(k_cdf_rows, dim3((h + CDF_ROWS - 1) / CDF_ROWS), dim3(CDF_COLS), 0, st, w, h, data, pdfX, cdfX, row_total);
+    hipLaunchKernelGGL(k_cdf_rows_scale, dim3((unsigned)(((size_t)w * h + 255) / 256)), dim3(256), 0, st, w, h, pdfX, cdfX, row_total);
     hipLaunchKernelGGL(k_cdf_cols, dim3(1), dim3(256), 0, st, h, row_total, pdfY, cdfY);
 }
 void fovpt_launch_math(hipStream_t st, int op, const float* a, const float* b, float* out, size_t n)

@@ -128,8 +128,11 @@ def test_hdr_probe_and_non_monotone_cdf_fallback(oracle):
 
 
 def test_build_cdf_on_device_matches_host_and_oracle(oracle):
-    """fovpt_set_probe_data: ProbeData::BuildCDF on the GPU, rows in parallel, left-to-right within a row."""
-    for data in (scenes.sky_probe(96, 40, seed=3), scenes.ambient_probe(320, 180, 2.5)):
+    """fovpt_set_probe_data: ProbeData::BuildCDF on the GPU, rows in parallel, left-to-right within a row.  The kernel works in
+    tiles of 8 rows x 256 columns: sizes below, at and across a tile, widths that are not a multiple of 4, a single row."""
+    rng = np.random.default_rng(17)
+    ragged = [rng.random((h, w, 4), dtype=np.float32) * np.float32(3.0) for (w, h) in ((1, 1), (7, 3), (255, 9), (256, 8), (257, 17), (773, 31), (1030, 5), (5, 4100))]
+    for data in [scenes.sky_probe(96, 40, seed=3), scenes.ambient_probe(320, 180, 2.5)] + ragged:
         h, w = data.shape[:2]
         r = renderer.SampleRenderer(scenes.cornell_box())
         p = r.setProbeData(data)

@@ -36,7 +36,7 @@ for _ in range(2):
 r.reset_stats()
 L = lib.load()
 BASE = 8 * 128 * 4 + 3 * 8 + 2 * 4 * 8
-NW = 8192
+NW = 32768
 cyc = np.zeros((2, 8, 16), np.uint64)
 hist = np.zeros((2, 8, 3, 64), np.uint64)
 wt = []
