@@ -146,6 +146,9 @@ def run_counter_passes(timeout_s=90):
     return out, "rocprofv3 --pmc child passes of this run (kernels serialised by the profiler)"
 
 
+FRAMES_IN_FLIGHT = [0]          # --frames-in-flight (0 = the library's default)
+
+
 def build_renderer(renderer, scenes, abi, tris, local_rank, rank, world, probe_kind="constant", seed=1234, scene="atrium"):
     model = scenes.atrium(tris, seed=seed, material="app") if scene == "atrium" else scenes.street(tris, material="app")
     # loadColor at frame resolution (main.cpp:175-187,229), or a seeded non-constant HDR sky of the same size
@@ -161,6 +164,7 @@ def build_renderer(renderer, scenes, abi, tris, local_rank, rank, world, probe_k
     cfg.spp_periphery, cfg.spp_middle, cfg.spp_fovea = SPP
     cfg.max_depth = 4
     cfg.rank, cfg.world = rank, world
+    cfg.frames_in_flight = FRAMES_IN_FLIGHT[0]
     r.config = cfg
     r.launchParams.frame.c.x, r.launchParams.frame.c.y = W // 2, H // 2
     return r, cfg, model, probe_data, probe
@@ -206,12 +210,15 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--no-counters", action="store_true", help="skip the rocprofv3 --pmc child passes (traffic / valu then come from profiles/, labelled imported)")
     ap.add_argument("--no-variants", action="store_true", help="skip the HDR-probe / moving-camera / 1 M / 3.8 M-triangle variants")
+    ap.add_argument("--frames-in-flight", type=int, default=0, choices=(0, 1, 2),
+                    help="fovpt_config.frames_in_flight for the timed region: 0 = the library's default (2), 1 = one frame at a time")
     ap.add_argument("--gather", choices=("packed", "reduce"), default="packed", help="N > 1: packed owned-pixel gather (default) or full-frame sum-reduce")
     ap.add_argument("--advance-subframe", action="store_true",
                     help="let render() advance subframe_index from frame to frame (new P-pass seeds every frame) instead of "
                          "resetting it to 0 as the shipped application does (main.cpp:402-407)")
     ap.add_argument("--child-frames", type=int, default=0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    FRAMES_IN_FLIGHT[0] = args.frames_in_flight
     if args.child_frames:
         return child_main(args.child_frames)
 
@@ -363,8 +370,10 @@ def main():
     prof_frames = max(5, min(50, args.steps))
     per_frame_ms = {}
     ps = None
-    for mode in (2, 1):
+    timed_fif = cfg.frames_in_flight
+    for mode, fif, label in ((2, timed_fif, "serialised"), (1, 1, "one_frame_in_flight"), (1, timed_fif, "overlapped")):
         cfg.profile = mode
+        cfg.frames_in_flight = fif
         r.config = cfg
         for _ in range(3):
             r.launchParams.frame.subframe_index = 0
@@ -376,11 +385,12 @@ def main():
             r.render_async()
         r.synchronize()
         ps = r.stats()
-        per_frame_ms["overlapped" if mode == 1 else "serialised"] = {
+        per_frame_ms[label] = {
             "generate": round(ps.ms_generate / prof_frames, 5), "traverse_closest": round(ps.ms_trace / prof_frames, 5),
             "traverse_occlusion": round(ps.ms_shadow / prof_frames, 5), "shade": round(ps.ms_shade / prof_frames, 5),
             "resolve": round(ps.ms_resolve / prof_frames, 5)}
     cfg.profile = 0
+    cfg.frames_in_flight = timed_fif
     r.config = cfg
     # k_traverse is the one traversal kernel (4 lanes per ray): closest-hit launches run on the main
     # stream (fovpt_stats books them under ms_trace), occlusion launches on the shadow stream
@@ -396,8 +406,11 @@ def main():
     bytes_per_launch = b_ray * (n_rays / max(1, n_launch))
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     ser = per_frame_ms["serialised"]
+    one = per_frame_ms["one_frame_in_flight"]
     launches_per_frame = n_launch / prof_frames
     avg_ms_serialised = (ser["traverse_closest"] + ser["traverse_occlusion"]) / max(1e-9, launches_per_frame)
+    avg_ms_one = (one["traverse_closest"] + one["traverse_occlusion"]) / max(1e-9, launches_per_frame)
+    in_flight = ms_k / prof_frames / max(1e-9, ms_per_step)           # k_traverse launches running at once, on average
 
     # counters: measured in this run, else imported from the committed profile (and labelled so)
     traffic, traffic_source, valu = None, counters_note, None
@@ -452,9 +465,9 @@ def main():
             "model_ms_per_frame": {"traverse_closest": round(model_closest, 4), "traverse_occlusion": round(model_anyhit, 4)},
             "measured_ms_per_frame_serialised": {"traverse_closest": ser["traverse_closest"], "traverse_occlusion": ser["traverse_occlusion"]},
             "reading": "a node step of a wave (16 rays in lockstep) is ~1000 cycles, ~62 % of it the wait for the two 16-byte node loads of "
-                       "its slowest quad, 16 % box test + rank, 8 % LDS push / pop, 14 % loop; a launch lasts 1.35-2.5 x its average "
-                       "wave's life because every wave gets the same number of 16-ray rounds and the slowest of 8192 ends 25-55 % after "
-                       "the mean (wave slots busy 40-74 %)",
+                       "its slowest quad, 16 % box test + rank, 8 % LDS push / pop, 14 % loop; a closest-hit launch is three one-wave "
+                       "workgroups per wave slot, started by the dispatcher as slots fall free, and lasts (waves per slot) x (a wave's "
+                       "life) / (share of the launch the slots are busy)",
             "source": "IMPORTED from profiles/r03_step_model.json (step anatomy, steps per wave, busy share: diagnostic builds); "
                       "measured_ms_per_frame_serialised from this run",
         }
@@ -472,9 +485,19 @@ def main():
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
         "avg_launch_ms": round(avg_ms, 5), "avg_launch_ms_serialised": round(avg_ms_serialised, 5),
         "frac_serialised": round(bytes_per_launch / (avg_ms_serialised * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if avg_ms_serialised > 0 else None,
+        "avg_launch_ms_one_frame_in_flight": round(avg_ms_one, 5),
+        "frac_one_frame_in_flight": round(bytes_per_launch / (avg_ms_one * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if avg_ms_one > 0 else None,
+        "launches_in_flight": round(in_flight, 3),
+        "frac_aggregate": round(bytes_per_launch * launches_per_frame / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+        "frac_note": "`achieved` / `frac` divide one launch's algorithmic bytes by its duration AS TIMED: with frames_in_flight = 2 the "
+                     "traversal launches of two frames and two streams share the chip (`launches_in_flight` of them at any time), so "
+                     "each lasts longer although more gets done per second (`value`).  `frac_one_frame_in_flight` is the same figure "
+                     "the way rounds 1-2 measured it, `frac_serialised` the kernel alone on the chip, `frac_aggregate` all traversal "
+                     "bytes of a frame over the frame interval",
         "launches_per_frame": launches_per_frame,
         "rays_per_launch": n_rays / max(1, n_launch), "algorithmic_bytes_per_ray": round(b_ray, 1),
         "per_frame_ms": per_frame_ms["overlapped"], "per_frame_ms_serialised": per_frame_ms["serialised"],
+        "per_frame_ms_one_frame_in_flight": per_frame_ms["one_frame_in_flight"],
         "valu": valu,
         "latency_model": latency_model,
     }
@@ -494,6 +517,7 @@ def main():
             "rays_per_frame": rays_total / args.steps,
             "subframe": "advancing" if args.advance_subframe else "reset to 0 every frame (as the shipped app)",
             "parallelism": "tile-shard x%d + %s gather" % (world, args.gather) if world > 1 else "single GPU",
+            "frames_in_flight": args.frames_in_flight or 2,
             "gather": gather_mode,
         },
         "roofline": roofline,

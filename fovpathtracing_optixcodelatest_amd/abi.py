@@ -147,6 +147,7 @@ class Config(C.Structure):
         ("spp_uniform", C.c_int32), ("max_depth", C.c_int32), ("accumulate", C.c_int32),
         ("rank", C.c_int32), ("world", C.c_int32), ("tile_w", C.c_int32), ("tile_h", C.c_int32),
         ("profile", C.c_int32), ("write_guides", C.c_int32), ("options", C.c_int32),
+        ("frames_in_flight", C.c_int32),      # 0 = library default (2), 1, 2
     ]
 
     @classmethod

@@ -67,11 +67,22 @@ struct StateSet {
     }
 };
 
+#ifndef FOVPT_LANES_DEFAULT
+#define FOVPT_LANES_DEFAULT 2
+#endif
+#define FOVPT_MAX_LANES 4
+
 struct fovpt_ctx {
     int device = 0;
     int num_cus = 256;
     hipStream_t stream = nullptr;          // main chain: generate, closest-hit traversal, shade
     hipStream_t shadow_stream = nullptr;   // occlusion rays of every bounce and the resolve: off the critical path
+    // Second LANE (round 3): consecutive jobs alternate between two (main, shadow) stream pairs, so the main chain of job k+1
+    // -- generate, closest-hit, shade, strictly one after the other -- runs BESIDE the main chain of job k instead of behind it:
+    // the launch gaps, ramps and tails of one chain are filled by the other.  Resolves stay in job order (each waits for the
+    // previous job's), and `shadow_stream` remains the one stream every finished frame is ordered on (fovpt_stream()).
+    hipStream_t lane_main[FOVPT_MAX_LANES] = {}, lane_shadow[FOVPT_MAX_LANES] = {};   // [0] = stream / shadow_stream
+    int lanes = FOVPT_LANES_DEFAULT;
     std::string err;
     fovpt_config cfg;
     // scene
@@ -101,7 +112,8 @@ struct fovpt_ctx {
     DevBuf comm_packed, comm_gathered;
     // Wavefront state, TWO sets used alternately by consecutive jobs: the tail of job k (its last occlusion
     // rays and its resolve, on the shadow stream) runs beside the head of job k+1 (generate, camera rays)
-    StateSet set[2];
+    StateSet set[FOVPT_MAX_LANES < 2 ? 2 : FOVPT_MAX_LANES];
+    unsigned nsets = 2;                    // = max(2, lanes)
     unsigned jobs = 0;                     // jobs issued so far; job j uses set[j & 1]
     int grid = 2048, grid_trace = 2048, grid_shadow = 1024, grid_shade = 1024;
     int async_last_shade = FOVPT_ASYNC_LAST_SHADE_DEFAULT;   // 1: the last shading launch of a job runs on the shadow stream (see run_job)
@@ -113,6 +125,9 @@ struct fovpt_ctx {
 };
 
 namespace {
+
+int fail(fovpt_ctx* c, int code, const char* fmt, ...);
+int sync_all(fovpt_ctx* c);
 
 int fail(fovpt_ctx* c, int code, const char* fmt, ...)
 {
@@ -126,6 +141,16 @@ int fail(fovpt_ctx* c, int code, const char* fmt, ...)
 }
 
 #define HIPCHK(c, x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return fail((c), FOVPT_E_DEVICE, "%s: %s", #x, hipGetErrorString(e_)); } while (0)
+
+int sync_all(fovpt_ctx* c)
+{
+    for (int l = 0; l < FOVPT_MAX_LANES; l++) {
+        if (c->lane_main[l]) HIPCHK(c, hipStreamSynchronize(c->lane_main[l]));
+        if (c->lane_shadow[l]) HIPCHK(c, hipStreamSynchronize(c->lane_shadow[l]));
+    }
+    if (c->shadow_stream) HIPCHK(c, hipStreamSynchronize(c->shadow_stream));      // last: the resolves wait for the lanes
+    return FOVPT_OK;
+}
 
 fovpt_config default_config()
 {
@@ -153,7 +178,7 @@ struct Timed {
     fovpt_ctx* c; int kind; hipStream_t st; hipEvent_t a = nullptr, b = nullptr;
     Timed(fovpt_ctx* c_, int k, hipStream_t s = nullptr) : c(c_), kind(k), st(s ? s : c_->stream)
     {
-        if (c->cfg.profile == 2) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->shadow_stream); }   // the kernel runs alone
+        if (c->cfg.profile == 2) (void)sync_all(c);   // the kernel runs alone
         if (c->cfg.profile) {
             a = get_event(c); b = get_event(c);
             if (a && b) (void)hipEventRecord(a, st);
@@ -200,7 +225,7 @@ void free_scene(fovpt_ctx* c)
 // each appending at most 256 entries.  Nothing can overflow a shard of slots / 8 + 512 entries.
 uint32_t shard_capacity(size_t slots) { return (uint32_t)(slots / FOVPT_SHARDS + 512); }
 
-int ensure_state(fovpt_ctx* c, StateSet& S, size_t slots, size_t launches)
+int ensure_state(fovpt_ctx* c, StateSet& S, size_t slots, size_t launches, hipStream_t st)
 {
     const size_t v = 16;
     HIPCHK(c, S.s_thr.reserve(slots * v)); HIPCHK(c, S.s_rng.reserve(slots * v));
@@ -224,7 +249,7 @@ int ensure_state(fovpt_ctx* c, StateSet& S, size_t slots, size_t launches)
     }
     if (!S.counters.p) {
         HIPCHK(c, S.counters.reserve(sizeof(Counters)));
-        HIPCHK(c, hipMemsetAsync(S.counters.p, 0, sizeof(Counters), c->stream));
+        HIPCHK(c, hipMemsetAsync(S.counters.p, 0, sizeof(Counters), st));      // (the main stream of the job that is about to use the set)
     }
     return FOVPT_OK;
 }
@@ -351,12 +376,17 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     fd.tile_w = c->cfg.tile_w > 0 ? c->cfg.tile_w : 8; fd.tile_h = c->cfg.tile_h > 0 ? c->cfg.tile_h : 4;
 
     if (slots == 0) return FOVPT_OK;
-    StateSet& S = c->set[c->jobs & 1u];
-    hipStream_t st = c->stream, ss = c->shadow_stream;
+    StateSet& S = c->set[c->jobs % c->nsets];
+    // lane = set, except for the chunk jobs of an oversized launch: their memsets / snapshot copies are ordered on
+    // shadow_stream, so they all run on lane 0 (as before round 3)
+    const int fif = c->cfg.frames_in_flight > 0 ? c->cfg.frames_in_flight : c->lanes;
+    const unsigned lanes = (unsigned)(fif < c->lanes ? fif : c->lanes);
+    const unsigned lane = (lanes > 1u && !chunked) ? c->jobs % lanes : 0u;
+    hipStream_t st = c->lane_main[lane], ss = c->lane_shadow[lane];
     // the set is free once the resolve of the job that used it last has run (reserve() may also free and
     // reallocate its buffers, which the runtime orders after all device work)
     if (S.used) HIPCHK(c, hipStreamWaitEvent(st, S.ev_done, 0));
-    int rc = ensure_state(c, S, (size_t)slots, (size_t)launches);
+    int rc = ensure_state(c, S, (size_t)slots, (size_t)launches, st);
     if (rc) return rc;
     c->jobs++;
     S.used = true;
@@ -391,7 +421,7 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
 #endif
     const int grid = c->grid;
     const uint32_t cap = shard_capacity((size_t)slots);
-    { Timed t(c, 0); fovpt_launch_generate(st, fd, ps, qa, cap, cnt, (uint32_t)slots, grid); }
+    { Timed t(c, 0, st); fovpt_launch_generate(st, fd, ps, qa, cap, cnt, (uint32_t)slots, grid); }
     // iterations: depth 0 .. max_depth-1, plus the reference's discarded segment and shadow-catcher
     // pass-throughs (which do not advance depth) when the scene holds a catcher
     int iters = c->cfg.max_depth + (c->any_catcher ? 1 + 24 : 0);
@@ -405,7 +435,7 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     // async_last_shade it runs on the shadow stream, in front of the last occlusion launch and the resolve, so the main stream
     // is free for the next job's generate and camera rays one shading launch earlier.
     const bool tail_async = c->async_last_shade != 0;
-    { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qa, sq[0], cap, cnt, 0, -1, c->grid_trace, (tail_async && iters == 1) ? S.ev_last_closest : nullptr); }
+    { Timed t(c, 1, st); fovpt_launch_traverse(st, sc, ps, qa, sq[0], cap, cnt, 0, -1, c->grid_trace, (tail_async && iters == 1) ? S.ev_last_closest : nullptr); }
     const int nsq = iters < FOVPT_NSQ ? iters : FOVPT_NSQ;        // (only that many buffers are allocated)
     for (int it = 0; it < iters; it++) {
         const bool last = it + 1 == iters;
@@ -416,14 +446,18 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
             if (it >= nsq) HIPCHK(c, hipStreamWaitEvent(st, S.ev_shadow[it - nsq], 0));
             // the events ride on the kernels' own completion signals (hipExtLaunchKernel): a separate
             // hipEventRecord would put a marker packet between shade(it) and closest(it+1), ~6 us on the critical path
-            { Timed t(c, 2); fovpt_launch_shade(st, fd, sc, ps, qa, qb, sq[it % nsq], cap, cnt, it, c->grid_shade, S.ev_shade[it]); }
+            { Timed t(c, 2, st); fovpt_launch_shade(st, fd, sc, ps, qa, qb, sq[it % nsq], cap, cnt, it, c->grid_shade, S.ev_shade[it]); }
             HIPCHK(c, hipStreamWaitEvent(ss, S.ev_shade[it], 0));
         }
         { Timed t(c, 3, ss); fovpt_launch_traverse(ss, sc, ps, qb, sq[it % nsq], cap, cnt, -1, it, c->grid_shadow, S.ev_shadow[it]); }
-        if (!last) { Timed t(c, 1); fovpt_launch_traverse(st, sc, ps, qb, sq[0], cap, cnt, it + 1, -1, c->grid_trace, (tail_async && it + 2 == iters) ? S.ev_last_closest : nullptr); }
+        if (!last) { Timed t(c, 1, st); fovpt_launch_traverse(st, sc, ps, qb, sq[0], cap, cnt, it + 1, -1, c->grid_trace, (tail_async && it + 2 == iters) ? S.ev_last_closest : nullptr); }
         const RayQueue tmp = qa; qa = qb; qb = tmp;
     }
-    { Timed t(c, 4, ss); fovpt_launch_resolve(ss, fd, ps, cnt, S.ev_done); }
+    // Every resolve runs on shadow_stream, whatever the lane: in job order (a later job's pixels overwrite, or blend with, an
+    // earlier one's), behind whatever the caller has queued on fovpt_stream() since the previous frame, and in front of what it
+    // queues next.  A job of the second lane joins it behind its last occlusion launch (which waited for its last shade).
+    if (ss != c->shadow_stream) HIPCHK(c, hipStreamWaitEvent(c->shadow_stream, S.ev_shadow[iters - 1], 0));
+    { Timed t(c, 4, c->shadow_stream); fovpt_launch_resolve(c->shadow_stream, fd, ps, cnt, S.ev_done); }
     HIPCHK(c, hipGetLastError());
     return FOVPT_OK;
 }
@@ -535,6 +569,13 @@ int fovpt_create(fovpt_ctx** out, int device)
     (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
     e = hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_hi);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->shadow_stream, hipStreamDefault, prio_lo);
+    if (const char* l = getenv("FOVPT_LANES")) { const int v = atoi(l); if (v >= 1 && v <= FOVPT_MAX_LANES) c->lanes = v; }
+    c->nsets = c->lanes < 2 ? 2u : (unsigned)c->lanes;
+    c->lane_main[0] = c->stream; c->lane_shadow[0] = c->shadow_stream;
+    for (int l = 1; l < c->lanes; l++) {
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->lane_main[l], hipStreamDefault, prio_hi);
+        if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->lane_shadow[l], hipStreamDefault, prio_lo);
+    }
     for (StateSet& S : c->set) {
         for (int k = 0; k <= FOVPT_MAX_ITERS && e == hipSuccess; k++) {
             e = hipEventCreateWithFlags(&S.ev_shade[k], hipEventDefault);
@@ -552,8 +593,7 @@ void fovpt_destroy(fovpt_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->shadow_stream) (void)hipStreamSynchronize(c->shadow_stream);
+    (void)sync_all(c);
     drain_events(c);
     for (hipEvent_t e : c->free_events) (void)hipEventDestroy(e);
     for (StateSet& S : c->set) {
@@ -572,6 +612,10 @@ void fovpt_destroy(fovpt_ctx* c)
                       &c->plan_owner, &c->plan_blocks, &c->plan_total, &c->plan_base, &c->plan_idx,
                       &c->comm_packed, &c->comm_gathered};
     for (DevBuf* b : bufs) b->release();
+    for (int l = 0; l < FOVPT_MAX_LANES; l++) {
+        if (c->lane_main[l] && c->lane_main[l] != c->stream) (void)hipStreamDestroy(c->lane_main[l]);
+        if (c->lane_shadow[l] && c->lane_shadow[l] != c->shadow_stream) (void)hipStreamDestroy(c->lane_shadow[l]);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->shadow_stream) (void)hipStreamDestroy(c->shadow_stream);
     delete c;
@@ -585,8 +629,7 @@ int fovpt_set_scene(fovpt_ctx* c, const fovpt_mesh_desc* meshes, int num_meshes,
     if (!c) return FOVPT_E_INVALID;
     if (!meshes || num_meshes <= 0) return fail(c, FOVPT_E_INVALID, "scene needs at least one mesh");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
+    { const int rc_ = sync_all(c); if (rc_) return rc_; }
     free_scene(c);
     uint64_t ntri = 0;
     bool any_tc = false;
@@ -702,8 +745,7 @@ int fovpt_set_probe(fovpt_ctx* c, int width, int height, const fovpt_float4* dat
     if (!data || !pdfX || !cdfX || !pdfY || !cdfY || width <= 0 || height <= 0 || !out)
         return fail(c, FOVPT_E_INVALID, "Probe Data is not valid");                         // Probe.h:104-105
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
+    { const int rc_ = sync_all(c); if (rc_) return rc_; }
     const size_t n = (size_t)width * height;
     HIPCHK(c, c->pr_pdfx.reserve(n * 4)); HIPCHK(c, c->pr_cdfx.reserve(n * 4));
     HIPCHK(c, c->pr_pdfy.reserve((size_t)height * 4)); HIPCHK(c, c->pr_cdfy.reserve((size_t)height * 4));
@@ -750,8 +792,7 @@ int fovpt_set_probe_data(fovpt_ctx* c, int width, int height, const fovpt_float4
     if (!c) return FOVPT_E_INVALID;
     if (!data || width <= 0 || height <= 0 || !out) return fail(c, FOVPT_E_INVALID, "Probe Data is not valid");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
+    { const int rc_ = sync_all(c); if (rc_) return rc_; }
     const size_t n = (size_t)width * height;
     HIPCHK(c, c->pr_pdfx.reserve(n * 4)); HIPCHK(c, c->pr_cdfx.reserve(n * 4));
     HIPCHK(c, c->pr_pdfy.reserve((size_t)height * 4)); HIPCHK(c, c->pr_cdfy.reserve((size_t)height * 4));
@@ -805,8 +846,7 @@ int fovpt_resize(fovpt_ctx* c, int width, int height, fovpt_frame_ptrs* out)
     if (width == 0 || height == 0) return FOVPT_OK;                                          // :231
     if (width < 0 || height < 0 || !out) return fail(c, FOVPT_E_INVALID, "bad resize arguments");
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
+    { const int rc_ = sync_all(c); if (rc_) return rc_; }
     const size_t n = (size_t)width * height;
     HIPCHK(c, c->fb_frame.reserve(n * 4)); HIPCHK(c, c->fb_accum.reserve(n * 16));
     HIPCHK(c, c->fb_color.reserve(n * 16)); HIPCHK(c, c->fb_normal.reserve(n * 16)); HIPCHK(c, c->fb_albedo.reserve(n * 16));
@@ -835,6 +875,7 @@ int fovpt_set_config(fovpt_ctx* c, const fovpt_config* cfg)
     if (cfg->world < 1 || cfg->rank < 0 || cfg->rank >= cfg->world) return fail(c, FOVPT_E_INVALID, "bad rank/world %d/%d", cfg->rank, cfg->world);
     if (cfg->spp_periphery < 1 || cfg->spp_middle < 1 || cfg->spp_fovea < 1 || cfg->spp_uniform < 1) return fail(c, FOVPT_E_INVALID, "spp must be >= 1");
     if (cfg->r_inner < 0 || cfg->r_outer < cfg->r_inner) return fail(c, FOVPT_E_INVALID, "bad radii");
+    if (cfg->frames_in_flight < 0 || cfg->frames_in_flight > FOVPT_MAX_LANES) return fail(c, FOVPT_E_INVALID, "frames_in_flight must be 0 (default), 1 or 2");
     if (cfg->options & ~(FOVPT_OPT_SKY_MISS | FOVPT_OPT_RUSSIAN_ROULETTE)) return fail(c, FOVPT_E_INVALID, "unknown option bits %d", cfg->options);
     c->cfg = *cfg;
     return FOVPT_OK;
@@ -1064,8 +1105,7 @@ int fovpt_synchronize(fovpt_ctx* c)
 {
     if (!c) return FOVPT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
+    { const int rc_ = sync_all(c); if (rc_) return rc_; }
     return FOVPT_OK;
 }
 
@@ -1073,8 +1113,7 @@ int fovpt_download(fovpt_ctx* c, const void* device_src, void* host_dst, size_t 
 {
     if (!c || !device_src || !host_dst) return FOVPT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
+    { const int rc_ = sync_all(c); if (rc_) return rc_; }
     HIPCHK(c, hipMemcpy(host_dst, device_src, n_bytes, hipMemcpyDeviceToHost));
     return FOVPT_OK;
 }
@@ -1083,8 +1122,7 @@ int fovpt_get_stats(fovpt_ctx* c, fovpt_stats* out)
 {
     if (!c || !out) return FOVPT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
+    { const int rc_ = sync_all(c); if (rc_) return rc_; }
     drain_events(c);
     c->stats.radiance_rays = c->stats.shadow_rays = c->stats.paths = 0;
     for (StateSet& S : c->set) {
@@ -1101,8 +1139,7 @@ int fovpt_reset_stats(fovpt_ctx* c)
 {
     if (!c) return FOVPT_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
+    { const int rc_ = sync_all(c); if (rc_) return rc_; }
     drain_events(c);
     for (StateSet& S : c->set)
         if (S.counters.p) HIPCHK(c, hipMemset((char*)S.counters.p + offsetof(Counters, stat_radiance), 0, sizeof(Counters) - offsetof(Counters, stat_radiance)));
@@ -1192,11 +1229,10 @@ int fovpt_debug_trace(fovpt_ctx* c, int n, const float* origins3, const float* d
     if (!c->has_scene) return fail(c, FOVPT_E_NO_SCENE, "fovpt_debug_trace without a scene");
     if (n == 0) return FOVPT_OK;
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
-    StateSet& S = c->set[c->jobs & 1u];
+    { const int rc_ = sync_all(c); if (rc_) return rc_; }
+    StateSet& S = c->set[c->jobs % c->nsets];
     const size_t slots = (size_t)n * FOVPT_SHARDS;                  // all rays go to shard 0: its capacity must hold them
-    int rc = ensure_state(c, S, slots, 1);
+    int rc = ensure_state(c, S, slots, 1, c->stream);
     if (rc) return rc;
     const uint32_t cap = shard_capacity(slots);
     hipStream_t st = c->stream;
@@ -1277,8 +1313,7 @@ int fovpt_debug_math(fovpt_ctx* c, int op, const float* a, const float* b, float
     if (b) HIPCHK(c, hipMemcpy(db, b, n * 4, hipMemcpyHostToDevice));
     else HIPCHK(c, hipMemset(db, 0, n * 4));
     fovpt_launch_math(c->stream, op, da, db, dout, n);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->shadow_stream));
+    { const int rc_ = sync_all(c); if (rc_) return rc_; }
     HIPCHK(c, hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
     return FOVPT_OK;
 }

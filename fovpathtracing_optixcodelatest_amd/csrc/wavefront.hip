@@ -997,15 +997,20 @@ __device__ inline void traverse_shadow_pool(const SceneView& sc, const PathState
 // iteration it_closest, one ray per QUAD of lanes (16 rays per wave).
 // (Dynamic work fetching with a global counter and per-lane replacement was measured and rejected: with
 // so few rays per resident lane per launch a returning atomic per wave costs more than the imbalance.)
+// (MODE 0: a closest-hit launch, 1: an occlusion launch, 2: both in one -- a build of the kernel for each, so that a wave of a
+// closest-hit launch neither fetches the occlusion queue's shard sizes before it starts nor carries that loop's registers.)
+template <int MODE>
 __global__ __launch_bounds__(FOVPT_TBLOCK, FOVPT_V_WAVES) void k_traverse(SceneView sc, PathState ps, RayQueue queue, ShadowQueue sq,
                                                                          uint32_t cap, Counters* __restrict__ cnt, int it_closest, int it_shadow)
 {
     __shared__ int s_stack[(FOVPT_STACK + 4) * FOVPT_TQUADS];  // + the end marker and three rows of slack above the top
+    if (MODE == 0) it_shadow = -1;
+    if (MODE == 1) it_closest = -1;
     ShardMap ms, mq;
-    ms.load(cnt, FOVPT_CNT_SQ(it_shadow >= 0 ? it_shadow : 0));
-    mq.load(cnt, FOVPT_CNT_Q(it_closest >= 0 ? it_closest : 0));
-    const uint32_t n_sh = it_shadow >= 0 ? ms.total() : 0u;
-    const uint32_t n_cl = it_closest >= 0 ? mq.total() : 0u;
+    if (MODE != 0) ms.load(cnt, FOVPT_CNT_SQ(it_shadow >= 0 ? it_shadow : 0));
+    if (MODE != 1) mq.load(cnt, FOVPT_CNT_Q(it_closest >= 0 ? it_closest : 0));
+    const uint32_t n_sh = (MODE != 0 && it_shadow >= 0) ? ms.total() : 0u;
+    const uint32_t n_cl = (MODE != 1 && it_closest >= 0) ? mq.total() : 0u;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (n_cl) atomicAdd(&cnt->stat_radiance, (unsigned long long)n_cl);
         if (n_sh) atomicAdd(&cnt->stat_shadow, (unsigned long long)n_sh);
@@ -1807,8 +1812,9 @@ void fovpt_launch_traverse(hipStream_t st, SceneView sc, PathState ps, RayQueue 
         const unsigned long long rounds = (8ull * cap + FOVPT_TQUADS - 1) / FOVPT_TQUADS;
         if ((unsigned long long)blocks > rounds) blocks = (int)((rounds + FOVPT_SHARDS - 1) / FOVPT_SHARDS * FOVPT_SHARDS);
     }
-    if (done) hipExtLaunchKernelGGL(k_traverse, dim3(blocks), dim3(FOVPT_TBLOCK), 0, st, nullptr, done, 0, sc, ps, queue, sq, cap, cnt, it_closest, it_shadow);
-    else hipLaunchKernelGGL(k_traverse, dim3(blocks), dim3(FOVPT_TBLOCK), 0, st, sc, ps, queue, sq, cap, cnt, it_closest, it_shadow);
+    auto kernel = it_shadow < 0 ? k_traverse<0> : it_closest < 0 ? k_traverse<1> : k_traverse<2>;
+    if (done) hipExtLaunchKernelGGL(kernel, dim3(blocks), dim3(FOVPT_TBLOCK), 0, st, nullptr, done, 0, sc, ps, queue, sq, cap, cnt, it_closest, it_shadow);
+    else hipLaunchKernelGGL(kernel, dim3(blocks), dim3(FOVPT_TBLOCK), 0, st, sc, ps, queue, sq, cap, cnt, it_closest, it_shadow);
 }
 void fovpt_launch_shade(hipStream_t st, const FrameDev& fd, SceneView sc, PathState ps, RayQueue queue_in, RayQueue queue_out,
                         ShadowQueue sq, uint32_t cap, Counters* cnt, int depth, int grid, hipEvent_t done)

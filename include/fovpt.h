@@ -164,6 +164,12 @@ typedef struct fovpt_config {
                                    not available with shadow-catcher materials         */
     int32_t options;            /* opt-in extensions beyond the reference's behaviour (0 = PT_sv5_ as shipped):
                                    FOVPT_OPT_SKY_MISS, FOVPT_OPT_RUSSIAN_ROULETTE                     */
+    int32_t frames_in_flight;   /* jobs (frames issued without fovpt_synchronize between them) whose main chains --
+                                   generate, closest hit, shade, one after the other -- may run BESIDE each other:
+                                   0 = the library's default (2), 1 = one frame at a time (lowest latency per frame),
+                                   2 = two (highest throughput: each chain fills the other's gaps; a frame then takes
+                                   about twice as long from first to last kernel).  Results do not depend on it: resolves
+                                   run in issue order, and fovpt_stream() is ordered behind every finished frame.        */
 } fovpt_config;
 
 /* fovpt_config.options.  Both are NON-PARITY modes with respect to the reference (it has neither); the CPU oracle

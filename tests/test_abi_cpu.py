@@ -57,6 +57,18 @@ def test_cpp_headers_compile_and_assert_layouts():
                    input=b'#include "fovpt.h"\nint main(void){return sizeof(fovpt_launch_params)==248?0:1;}\n', check=True)
 
 
+def test_config_mirror_matches_the_header(tmp_path):
+    """abi.Config is fovpt_config member for member (the header compiled by gcc says where each member lies)."""
+    names = [f[0] for f in abi.Config._fields_]
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "fovpt.h"\nint main(void){printf("%zu", sizeof(fovpt_config));' + "".join(
+        'printf(" %%zu", offsetof(fovpt_config, %s));' % n for n in names) + "return 0;}\n"
+    exe = str(tmp_path / "cfg_layout")
+    subprocess.run(["gcc", "-std=c99", "-x", "c", "-I", os.path.join(ROOT, "include"), "-", "-o", exe], input=src.encode(), check=True)
+    got = [int(x) for x in subprocess.check_output([exe]).split()]
+    assert got[0] == C.sizeof(abi.Config)
+    assert got[1:] == [getattr(abi.Config, n).offset for n in names]
+
+
 def test_default_config_is_the_shipped_reference(so):
     c = abi.Config.reference_default()
     assert (c.uniform, c.r_inner, c.r_outer) == (0, 74, 241)                 # SimplePathtracer.cpp:20-23

@@ -172,6 +172,44 @@ def test_torch_external_stream_orders_after_the_frame():
     r.close()
 
 
+@pytest.mark.parametrize("accumulate", [0, 1])
+def test_frames_in_flight_do_not_change_the_frames(accumulate):
+    """fovpt_config.frames_in_flight: with two frames in flight the main chains of consecutive frames run beside each other
+    on two stream pairs; every frame must still come out as with one -- resolves in issue order (progressive accumulation
+    makes frame k depend on frame k-1), and work the caller queues on fovpt_stream() between two frames ordered between them
+    (each frame is copied out and the ONE frame buffer cleared right behind it, six frames back to back, no host sync)."""
+    import torch
+    size = (320, 180)
+    n = 6
+    got = {}
+    for fif in (1, 2):
+        cfg = cfg_foveated(24, 80, (1, 2, 4))
+        cfg.accumulate = accumulate
+        cfg.frames_in_flight = fif
+        r = make_gpu(scenes.atrium(9000), scenes.sky_probe(), scenes.ATRIUM_CAMERA, size, cfg, gaze=(200, 70))
+        frame = torch.zeros(size[0] * size[1], dtype=torch.int32, device="cuda")
+        ext = torch.cuda.ExternalStream(r.stream)
+        copies = []
+        cam = scenes.ATRIUM_CAMERA
+        for k in range(n):
+            eye = list(cam["eye"]); eye[0] += 3.0 * k * (1 - accumulate)         # a moving camera unless the frames accumulate
+            r.setCamera(renderer.Camera(eye, cam["lookat"], cam["up"], cam["fovy"], size[0] / size[1]))
+            r.launchParams.frame.subframe_index = k if accumulate else 0
+            r.launchParams.frame.frame_buffer = frame.data_ptr()
+            with torch.cuda.stream(ext):
+                r.render_async()
+                copies.append(frame.clone())
+                frame.zero_()
+        ext.synchronize()
+        got[fif] = ([c.cpu() for c in copies], r.downloadAccum().copy())
+        r.close()
+    for a, b in zip(got[1][0], got[2][0]):
+        assert torch.equal(a, b) and int((a != 0).sum()) > 0.9 * a.numel()
+    assert _eq(got[1][1], got[2][1])
+    if not accumulate:
+        assert not torch.equal(got[1][0][0], got[1][0][-1])                       # (the camera did move)
+
+
 def test_bench_two_rank_rehearsal_gathers_the_full_frame():
     """bench.py's N > 1 path end to end on ONE GPU: two ranks share device 0 and talk over gloo
     (FOVPT_BENCH_REHEARSAL; RCCL refuses two ranks per device).  Rank 0's gathered frame must equal the

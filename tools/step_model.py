@@ -11,7 +11,8 @@ import json, re, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cyc = open(os.path.join(ROOT, "profiles", sys.argv[1] if len(sys.argv) > 1 else "r03_step_cycles.txt")).read()
 tl = open(os.path.join(ROOT, "profiles", sys.argv[2] if len(sys.argv) > 2 else "r03_wave_timeline_c3.txt")).read()
-out = {"source": "tools/step_model.py from profiles/r03_step_cycles.txt (stamped sample of waves) and profiles/r03_wave_timeline_c3.txt (unstamped build)",
+out = {"source": "tools/step_model.py from profiles/%s (stamped sample of waves) and profiles/%s (unstamped build)" % (
+           sys.argv[1] if len(sys.argv) > 1 else "r03_step_cycles.txt", sys.argv[2] if len(sys.argv) > 2 else "r03_wave_timeline_c3.txt"),
        "launches": {}}
 blocks = re.split(r"\n(?=(?:closest|any-hit) it \d)", cyc)
 for b in blocks:
@@ -48,7 +49,8 @@ for key, d in out["launches"].items():
     if "node_step_cycles" in d and "unstamped" in d:
         chain = d["node_steps_per_wave"] * d["node_step_cycles"]["total"] + d["leaf_steps_per_wave"] * d.get("leaf_step_cycles", {"total": 0})["total"]
         life_us = chain / d["share_of_wave_life_in_steps"] / (d["clock_ghz"] * 1e3)
-        d["model"] = {"chain_cycles_per_wave": round(chain), "wave_life_us": round(life_us, 1), "launch_us": round(life_us / d["unstamped"]["wave_slots_busy"], 1),
+        rounds = max(1.0, d["unstamped"]["waves"] / 8192.0)      # one-wave workgroups: waves per wave slot
+        d["model"] = {"chain_cycles_per_wave": round(chain), "wave_life_us": round(life_us, 1), "launch_us": round(life_us * rounds / d["unstamped"]["wave_slots_busy"], 1),
                       "measured_wave_life_us": d["unstamped"]["wave_life_mean_us"], "measured_launch_us": d["unstamped"]["launch_us"],
                       "load_wait_share_of_node_step": round(d["node_step_cycles"]["load_wait"] / d["node_step_cycles"]["total"], 3)}
 json.dump(out, open(os.path.join(ROOT, "profiles", "r03_step_model.json"), "w"), indent=1)

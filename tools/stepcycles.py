@@ -37,6 +37,7 @@ r.reset_stats()
 L = lib.load()
 BASE = 8 * 128 * 4 + 3 * 8 + 2 * 4 * 8
 NW = 32768
+SLOTS = 256 * 32                       # wave slots of the chip: 256 CUs x 4 SIMDs x 8
 cyc = np.zeros((2, 8, 16), np.uint64)
 hist = np.zeros((2, 8, 3, 64), np.uint64)
 wt = []
@@ -100,6 +101,7 @@ for k in range(2):
             lifeus = (w[:, 1] - w[:, 0]) / 100.0
             endus = (w[:, 1] - t0) / 100.0
             startus = (w[:, 0] - t0) / 100.0
+            slots = min(len(w), SLOTS)             # one-wave workgroups: more waves than slots, the dispatcher starts one as one ends
             print("          launch: %d waves, first start -> last end %.1f us; wave start mean %.1f (p99 %.1f) us, wave end mean %.1f p10 %.1f p50 %.1f p90 %.1f max %.1f us;"
                   " life mean %.1f us; wave slots busy %.1f %% of the span" % (len(w), span, startus.mean(), np.percentile(startus, 99), endus.mean(),
-                  np.percentile(endus, 10), np.percentile(endus, 50), np.percentile(endus, 90), endus.max(), lifeus.mean(), 100 * lifeus.sum() / (len(w) * span)))
+                  np.percentile(endus, 10), np.percentile(endus, 50), np.percentile(endus, 90), endus.max(), lifeus.mean(), 100 * lifeus.sum() / (slots * span)))
