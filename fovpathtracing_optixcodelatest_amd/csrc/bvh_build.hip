@@ -439,7 +439,7 @@ __global__ void k_collapse4(int nwork, const Work4* __restrict__ work_in, Work4*
         BvhChild& C = nd.c[k];
         C.lox = C.loy = C.loz = C.hix = C.hiy = C.hiz = INFINITY;   // empty slot: a point at +inf never passes the slab test
         C.code = leaf_code(0, 1);
-        C.pad = 0;
+        C.pad = (uint32_t)k;                                         // closest-hit tie rank: distinct within the node
     }
     for (int k = 0; k < nch; k++) {
         const int x = ch[k];
@@ -471,6 +471,73 @@ __global__ void k_collapse4(int nwork, const Work4* __restrict__ work_in, Work4*
     atomicAdd(&stats[1], 1u);
 }
 
+// ---- child order for occlusion rays (after Ize & Hansen 2011, "RTSAH traversal order for occlusion rays") -----------------
+// An occlusion ray ends at its FIRST front-facing hit and visits a wide node's children in storage order (sorting them by
+// distance was measured slower, EXPERIMENTS.md), so storage order is free to be the order that ends rays soonest: bottom-up
+// every subtree gets P = the chance that a ray passing its box is stopped inside and C = what finding out costs, in node steps,
+//     leaf:  P = min(1, triangle area / box area)  (random lines through a box hit a one-sided triangle's front with A / SA),  C = leaf step
+//     node:  children in descending P / C  (the classic rule for "test until one succeeds");
+//            h_k = SA_k / SA_node,   C = 1 + sum_k prod_{m<k} (1 - h_m P_m) h_k C_k,   P = 1 - prod_k (1 - h_k P_k)
+// One launch per level of the wide tree, deepest first (a level's nodes are contiguous).  No order can change a result
+// (include/fovpt.h: the hit is defined by (t, primitive id), occlusion by existence).  Closest-hit rays visit nearest first and
+// rank children they enter at the SAME distance -- rays that start inside several boxes, i.e. most secondary rays near the top of
+// the tree -- by BvhChild::pad, which keeps the slot the collapse chose: ranking those by this pass's order costs the street's
+// closest-hit launches 6 % (the atrium's nothing), smallest or largest box first is no better (EXPERIMENTS.md).
+#ifndef FOVPT_COST_LEAF_STEP
+#define FOVPT_COST_LEAF_STEP 1.4f          // a leaf step in node steps (measured: 1.36, profiles/r03_step_cycles.txt)
+#endif
+__global__ void k_order_children(uint32_t first, uint32_t count, BvhNode4* __restrict__ nodes, const TriRec* __restrict__ tris, float2* __restrict__ pc)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const uint32_t i = first + t;
+    const BvhNode4 nd = nodes[i];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    float P[4], C[4], sa[4], key[4];
+    for (int k = 0; k < 4; k++) {
+        const BvhChild& c = nd.c[k];
+        P[k] = 0.f; C[k] = 1.f; sa[k] = 0.f; key[k] = -1.f;
+        if (!(c.lox < INFINITY)) continue;                                       // empty slot: stays behind the used ones
+        lo[0] = fminf(lo[0], c.lox); lo[1] = fminf(lo[1], c.loy); lo[2] = fminf(lo[2], c.loz);
+        hi[0] = fmaxf(hi[0], c.hix); hi[1] = fmaxf(hi[1], c.hiy); hi[2] = fmaxf(hi[2], c.hiz);
+        const float dx = c.hix - c.lox, dy = c.hiy - c.loy, dz = c.hiz - c.loz;
+        sa[k] = 2.0f * (dx * dy + dy * dz + dz * dx);
+        if (c.code < 0) {
+            const uint32_t lcode = (uint32_t)~c.code, n = (lcode & 7u) + 1u, t0 = (lcode >> 3) / 3u;
+            float area = 0.f;
+            for (uint32_t j = 0; j < n; j++) {
+                const TriRec& T = tris[t0 + j];
+                const float cx = T.e1y * T.e2z - T.e1z * T.e2y, cy = T.e1z * T.e2x - T.e1x * T.e2z, cz = T.e1x * T.e2y - T.e1y * T.e2x;
+                area += 0.5f * sqrtf(cx * cx + cy * cy + cz * cz);
+            }
+            P[k] = sa[k] > 0.f ? fminf(1.0f, area / sa[k]) : 1.0f;
+            C[k] = FOVPT_COST_LEAF_STEP;
+        } else {
+            const float2 v = pc[c.code];
+            P[k] = v.x; C[k] = v.y;
+        }
+        key[k] = P[k] / C[k];
+    }
+    const float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+    const float sa_node = 2.0f * (dx * dy + dy * dz + dz * dx);
+    int ord[4] = {0, 1, 2, 3};
+    for (int a = 1; a < 4; a++)                                                   // insertion sort, descending, stable
+        for (int b = a; b > 0 && key[ord[b]] > key[ord[b - 1]]; b--) { const int tmp = ord[b]; ord[b] = ord[b - 1]; ord[b - 1] = tmp; }
+    float pass = 1.0f, cost = 1.0f;
+    BvhNode4 out;
+    for (int k = 0; k < 4; k++) {
+        const int j = ord[k];
+        out.c[k] = nd.c[j];
+        out.c[k].pad = (uint32_t)j;              // closest-hit rays keep ranking equal entry distances by the slot the collapse chose (see below)
+        if (key[j] < 0.f) continue;
+        const float h = sa_node > 0.f ? fminf(1.0f, sa[j] / sa_node) : 1.0f;
+        cost += pass * h * C[j];
+        pass *= 1.0f - h * P[j];
+    }
+    nodes[i] = out;
+    pc[i] = make_float2(1.0f - pass, cost);
+}
+
 // tiny scenes (n <= FOVPT_LEAF_MAX): a root whose first child is the only leaf
 __global__ void k_emit_tiny(int n, const Box* __restrict__ boxes, BvhNode4* __restrict__ nodes, uint32_t* __restrict__ stats, uint32_t* __restrict__ leaf_pos)
 {
@@ -482,7 +549,7 @@ __global__ void k_emit_tiny(int n, const Box* __restrict__ boxes, BvhNode4* __re
         BvhChild& C = nd.c[k];
         C.lox = C.loy = C.loz = C.hix = C.hiy = C.hiz = INFINITY;
         C.code = leaf_code(0, 1);
-        C.pad = 0;
+        C.pad = (uint32_t)k;
     }
     nd.c[0].lox = u.lo[0]; nd.c[0].loy = u.lo[1]; nd.c[0].loz = u.lo[2];
     nd.c[0].hix = u.hi[0]; nd.c[0].hiy = u.hi[1]; nd.c[0].hiz = u.hi[2];
@@ -627,6 +694,10 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
     Work4 *work_a = nullptr, *work_b = nullptr;
     DpCost* dp = nullptr;
     std::vector<uint32_t> round_end;           // PLOC: internal nodes created up to and including each round
+    std::vector<uint32_t> level_first;         // wide tree: index of the first node of every level (+ the node count at the end)
+    const char* order_env = getenv("FOVPT_BVH_ORDER");                            // 0: keep the collapse's child order (A/B)
+    const bool order_children = !order_env || atoi(order_env) != 0;
+    float2* order_pc = nullptr;
     uint32_t* dp_arrive = nullptr;
     uint32_t* counters = nullptr;
     BvhNode4* nodes = nullptr;
@@ -778,12 +849,15 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
         HC(hipMemcpyAsync(counters, h_counters, 8, hipMemcpyHostToDevice, st));
         uint32_t nwork = 1;
         int levels = 0;
+        level_first.push_back(0u);
+        level_first.push_back(1u);             // the root is node 0; the nodes of level L + 1 are allocated by the launch of level L
         while (nwork > 0) {
             hipLaunchKernelGGL(k_collapse4, dim3((nwork + B - 1) / B), dim3(B), 0, st, (int)nwork, work_a, work_b, counters, left, right,
                                size_int, node_first, leaf_pos, boxes, vals_s, ibox, dp, nodes, stats);
             HC(hipMemcpyAsync(h_counters, counters, 8, hipMemcpyDeviceToHost, st));
             HC(hipStreamSynchronize(st));
             nwork = h_counters[1];
+            if (nwork > 0) level_first.push_back(h_counters[0]);
             h_counters[1] = 0;
             HC(hipMemcpyAsync(counters + 1, &h_counters[1], 4, hipMemcpyHostToDevice, st));
             Work4* t = work_a; work_a = work_b; work_b = t;
@@ -792,6 +866,16 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
     }
     hipLaunchKernelGGL(k_emit_tris_generic, dim3(gn), dim3(B), 0, st, flat, mesh_of_prim, vals_s, ref_prim, leaf_pos, n, tris);
     HC(hipGetLastError());
+    if (order_children && level_first.size() >= 2) {
+        // children in the order that ends occlusion rays soonest: one launch per level, deepest first
+        const uint32_t total = level_first.back();
+        HC(hipMalloc(&order_pc, sizeof(float2) * (size_t)total));
+        for (size_t L = level_first.size() - 1; L-- > 0;) {
+            const uint32_t first = level_first[L], count = level_first[L + 1] - first;
+            if (count) hipLaunchKernelGGL(k_order_children, dim3((count + B - 1) / B), dim3(B), 0, st, first, count, nodes, tris, order_pc);
+        }
+        HC(hipGetLastError());
+    }
     HC(hipMemcpyAsync(h_stats, stats, 8, hipMemcpyDeviceToHost, st));
     HC(hipStreamSynchronize(st));
 
@@ -826,7 +910,7 @@ fail:
     (void)hipFree(parent_leaf); (void)hipFree(rfirst); (void)hipFree(rlast); (void)hipFree(temp); (void)hipFree(nodes); (void)hipFree(tris);
     (void)hipFree(c_node); (void)hipFree(t_node); (void)hipFree(nn); (void)hipFree(c_box); (void)hipFree(t_box); (void)hipFree(valid); (void)hipFree(pos);
     (void)hipFree(node_counter); (void)hipFree(size_int); (void)hipFree(leaf_pos); (void)hipFree(node_first); (void)hipFree(node_depth);
-    (void)hipFree(dp); (void)hipFree(dp_arrive);
+    (void)hipFree(dp); (void)hipFree(dp_arrive); (void)hipFree(order_pc);
     (void)hipFree(side_int); (void)hipFree(side_leaf); (void)hipFree(scan_temp); (void)hipFree(work_a); (void)hipFree(work_b); (void)hipFree(counters);
     return rc;
 }

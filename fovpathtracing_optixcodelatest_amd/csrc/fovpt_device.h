@@ -59,7 +59,8 @@ struct alignas(16) BvhChild {
     float lox, loy, loz, hix;
     float hiy, hiz;
     int32_t code;
-    uint32_t pad;
+    uint32_t pad;                 // 0..3, distinct within a node: where closest-hit rays rank this child among children they enter at the
+                                  // same distance (the two lowest bits of the traversal's sort key; equal keys would collide on the stack)
 };
 struct alignas(16) BvhNode4 {
     BvhChild c[4];

@@ -799,7 +799,7 @@ __device__ inline void node_step(const SceneView& sc, const RayT& r, const QuadL
         // (the sign of a difference is the comparison); misses sort first.  The visiting order
         // does not change the result, only the amount of pruning.
         uint32_t key;
-        asm("v_and_or_b32 %0, %1, -4, %2" : "=v"(key) : "v"(h ? __float_as_uint(t) : 0u), "v"(q.j));
+        asm("v_and_or_b32 %0, %1, -4, %2" : "=v"(key) : "v"(h ? __float_as_uint(t) : 0u), "v"(__float_as_uint(b.w)));      // b.w: the child's tie rank 0..3 (BvhChild::pad)
         const int lt = ((int)(quad_rot1(key) - key) >> 31) + ((int)(quad_rot2(key) - key) >> 31) + ((int)(quad_rot3(key) - key) >> 31);
         row = (lt << ROWSHIFT) + 3 * ROWB;             // 3 - (number of keys below mine)
     }

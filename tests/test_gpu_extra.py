@@ -630,6 +630,25 @@ def test_hierarchy_choice_does_not_change_the_frame(oracle, monkeypatch):
         nodes[kind] = r.stats().num_bvh_nodes
         r.close()
     assert 0 < nodes["ploc"] and 0 < nodes["lbvh"] and nodes["ploc"] != nodes["lbvh"]      # two different trees were built
+    # ... nor does the order of a wide node's children (by default the one that ends occlusion rays soonest, k_order_children;
+    # FOVPT_BVH_ORDER=0 keeps the order of the collapse), seen through the frame and ray by ray through the production kernel
+    monkeypatch.setenv("FOVPT_BVH", "ploc")
+    rng = np.random.default_rng(5)
+    n = 4096
+    org = rng.uniform(-1.0, 1.0, (n, 3)).astype(np.float32) * np.float32([1700.0, 600.0, 800.0]) + np.float32([0.0, 700.0, 0.0])   # inside the atrium
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    traces = []
+    for order in ("0", "1"):
+        monkeypatch.setenv("FOVPT_BVH_ORDER", order)
+        r = make_gpu(model, probe, scenes.ATRIUM_CAMERA, size, cfg)
+        r.render()
+        assert _bits_equal(r.downloadAccum(), F.accum) and np.array_equal(r.downloadPixels(), F.frame), order
+        traces.append(r.debug_trace(org, d))
+        r.close()
+    for a, b in zip(traces[0], traces[1]):
+        assert np.array_equal(np.asarray(a).view(np.uint8), np.asarray(b).view(np.uint8))
+    assert 0.05 < np.mean(traces[0][2]) < 0.999                                            # (some of those rays are occluded, some not)
 
 
 @pytest.mark.gpu

@@ -17,7 +17,7 @@ t = time.time(); r.setProbe(renderer.ProbeData(scenes.sky_probe(W, H, seed=11) i
 cfg = abi.Config.reference_default()
 cfg.r_inner, cfg.r_outer = 148, 482
 cfg.spp_periphery, cfg.spp_middle, cfg.spp_fovea = 1, 2, 8
-for profile in (0, 1):
+for profile in [int(x) for x in os.environ.get("FOVPT_QP_PROFILES", "0,1").split(",")]:      # 2: every kernel alone
     cfg.profile = profile
     r.config = cfg
     r.launchParams.frame.c.x, r.launchParams.frame.c.y = W // 2, H // 2
@@ -36,8 +36,8 @@ for profile in (0, 1):
     print("profile", profile, "ms/frame %.3f" % (dt * 1e3), "rays/frame %.0f" % rays, "Mray/s %.1f" % (rays / dt / 1e6),
           "paths", s.paths // frames, "rad", s.radiance_rays // frames, "shadow", s.shadow_rays // frames)
     if profile:
-        print("  per-frame ms: gen %.3f closest %.3f occlusion(async) %.3f shade %.3f resolve %.3f" % tuple(
-            x / frames for x in (s.ms_generate, s.ms_trace, s.ms_shadow, s.ms_shade, s.ms_resolve)))
+        print("  per-frame ms%s: gen %.3f closest %.3f occlusion(async) %.3f shade %.3f resolve %.3f" % ((("", "", " (alone)")[profile],) + tuple(
+            x / frames for x in (s.ms_generate, s.ms_trace, s.ms_shadow, s.ms_shade, s.ms_resolve))))
 print("bvh nodes", s.num_bvh_nodes, "depth", s.bvh_max_depth, "build ms %.2f" % s.ms_bvh_build, "bvh MB %.1f" % (s.bvh_bytes / 1e6), "tri MB %.1f" % (s.tri_bytes / 1e6))
 acc = r.downloadAccum()
 print("accum mean", acc[..., :3].mean(axis=(0, 1)), "max", acc[..., :3].max(), "finite", np.isfinite(acc).all())
