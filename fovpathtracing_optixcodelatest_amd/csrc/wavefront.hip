@@ -1024,7 +1024,9 @@ __global__ __launch_bounds__(FOVPT_TBLOCK, FOVPT_V_WAVES) void k_traverse(SceneV
     if (threadIdx.x == 0) s_cyc_last = 0u;
     __syncthreads();
     Cyc C;
-    C.init(FOVPT_V_CYCLES != 3 && __builtin_amdgcn_readfirstlane((blockIdx.x < 256u && threadIdx.x < 64u) ? 1 : 0) != 0);   // 3: wave start / end times only
+    // the sample: wave 0 of ~256 workgroups spread evenly over the grid (the first workgroups of a launch get the most rounds)
+    const uint32_t cyc_every = gridDim.x >= 512u ? gridDim.x / 256u : 1u;
+    C.init(FOVPT_V_CYCLES != 3 && __builtin_amdgcn_readfirstlane((blockIdx.x % cyc_every == 0u && threadIdx.x < 64u) ? 1 : 0) != 0);   // 3: wave start / end times only
     const unsigned long long real0 = __builtin_amdgcn_s_memrealtime();      // every wave: when it starts and ends (100 MHz)
     const uint32_t life0 = cyc_stamp();
 #endif

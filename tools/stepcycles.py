@@ -4,7 +4,7 @@ The build stamps s_memtime (shader cycles) inside node_step / leaf_step of k_tra
   node step:  gap (loop overhead since the previous step) | load (address -> both 16-byte loads arrived)
               | alu (box test, hit mask, rank) | lds (stack write, wave barrier, pop)
   leaf step:  gap | load (triangle record arrived) | rest (Moeller-Trumbore, merge, pop)
-in a SAMPLE of the waves (wave 0 of the first 256 blocks: stamping every wave slows the launch 4-8 x) and sums them per wave
+in a SAMPLE of the waves (wave 0 of ~256 workgroups spread over the grid: stamping every wave slows the launch 4-8 x) and sums them per wave
 (wave-level: a wave steps its 16 rays in lockstep).  With FOVPT_V_CYCLES=2 it also fills histograms of the load wait and of
 whole steps.  Every wave records when it started and ended (s_memrealtime), which gives the ramp and the tail of a launch.
 
