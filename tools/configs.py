@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from fovpathtracing_optixcodelatest_amd import abi, renderer, scenes
 
-def run(name, tris, size, cfg, material="app", frames=10, eyes=1, gaze=None, scene="atrium"):
+def run(name, tris, size, cfg, material="app", frames=40, eyes=1, gaze=None, scene="atrium"):      # (two frames are in flight: few frames would time the pipeline filling up)
     W, H = size
     t = time.time(); model = scenes.atrium(tris, material=material) if scene == "atrium" else scenes.street(tris, material=material)
     r = renderer.SampleRenderer(model)
@@ -46,16 +46,16 @@ which = sys.argv[1:] or ["C2", "C3", "C4", "C5"]
 if "C2" in which: run("C2", 262144, (1920, 1080), uni, material="diffuse")
 if "C3" in which: run("C3", 262144, (1920, 1080), fov(148, 482))
 if "C4" in which: run("C4", 3800000, (2560, 1440), fov(197, 643))
-if "C5" in which: run("C5", 3800000, (2160, 2160), fov(296, 964, depth=8), eyes=2, frames=5)
+if "C5" in which: run("C5", 3800000, (2160, 2160), fov(296, 964, depth=8), eyes=2, frames=10)
 if "C4S" in which: run("C4-street", 3800000, (2560, 1440), fov(197, 643), scene="street")
-if "C5S" in which: run("C5-street", 3800000, (2160, 2160), fov(296, 964, depth=8), eyes=2, frames=5, scene="street")
+if "C5S" in which: run("C5-street", 3800000, (2160, 2160), fov(296, 964, depth=8), eyes=2, frames=10, scene="street")
 if "REF" in which:   # the reference's own shipped settings: 74/241, 8/16/32 spp
     c = abi.Config.reference_default(); run("REF-shipped", 262144, (1920, 1080), c)
 if "U4" in which:    # FOV_OFF as shipped: uniform 4 spp
-    c = abi.Config.reference_default(); c.uniform = 1; run("FOV_OFF-4spp", 262144, (1920, 1080), c, frames=5)
+    c = abi.Config.reference_default(); c.uniform = 1; run("FOV_OFF-4spp", 262144, (1920, 1080), c, frames=20)
 if "PUBF" in which:  # the reference's published foveated benchmark: 3840x2160, radii 74/241, spp 32/16/8 (133.7 ms on its RTX GPU, Sponza)
     c = abi.Config.reference_default(); c.spp_periphery, c.spp_middle, c.spp_fovea = 8, 16, 32
-    run("published-fov-4K-32/16/8", 262144, (3840, 2160), c, frames=5)
+    run("published-fov-4K-32/16/8", 262144, (3840, 2160), c, frames=20)
 if "PUBU" in which:  # the reference's published uniform benchmark: 3840x2160, 32 spp (3405 ms on its RTX GPU, Sponza)
     c = abi.Config.reference_default(); c.uniform, c.spp_uniform = 1, 32
     run("published-uniform-4K-32spp", 262144, (3840, 2160), c, frames=2)
