@@ -102,6 +102,9 @@ public:
     // ---- multi-GPU (new with this library; the reference is single-GPU): one SampleRenderer per GPU / process, rank and
     // world in fovpt_config, the framebuffer gathered over RCCL on the library's stream (include/fovpt.h, fovpt_comm_*)
     void renderAsync() { check(fovpt_render(ctx, reinterpret_cast<fovpt_launch_params*>(&launchParams))); }   // render() without the sync
+    // frames issued with renderAsync() run up to two at a time (fovpt_config.frames_in_flight: 2 = throughput, the default;
+    // 1 = lowest latency per frame); they complete in order on `stream`
+    void setFramesInFlight(int n) { fovpt_config c = config(); c.frames_in_flight = n; setConfig(c); }
     void commInit(const void* uniqueId, int rank, int world) { check(fovpt_comm_init(ctx, uniqueId, rank, world)); }
     // gathers the frame just rendered (the renderer's current frame_buffer) onto `root`; fullFrame: device memory, root only
     void gatherFrame(int root, uint32_t* fullFrame)
