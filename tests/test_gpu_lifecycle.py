@@ -621,6 +621,7 @@ def test_random_lifecycle(oracle, seed):
                 r_i = int(rng.integers(1, 25))
                 cfg = cfg_foveated(r_i, r_i + int(rng.integers(1, 40)), tuple(int(x) for x in rng.integers(1, 5, 3)), max_depth=int(rng.integers(1, 5)))
             cfg.accumulate = int(rng.random() < 0.4)
+            cfg.frames_in_flight = int(seed * 7 + step) % 3              # 0 (= the default, 2), 1 or 2: never changes a frame
             r.config = cfg
         elif op == 4:                                                 # the application resets the subframe counter
             sub = int(rng.integers(0, 3))
