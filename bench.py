@@ -79,8 +79,10 @@ def host_cpu_share():
 PMC_PASSES = {
     "fetch": ["FETCH_SIZE"],                                  # TCC: 3 of the 4 slots -> its own pass (MI355X_MICROARCH.md, PMC slots)
     "write": ["WRITE_SIZE"],
-    "valu": ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES"],
+    "valu": ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_INSTS_VMEM_RD"],
+    "ta": ["TA_TA_BUSY_sum", "TA_FLAT_READ_WAVEFRONTS_sum"],      # two TA counters per pass fit the block's slots; four do not (error 38)
 }
+CUS = 256
 
 
 def run_counter_passes(timeout_s=90):
@@ -437,6 +439,26 @@ def main():
                 "per_kernel_lane_use": {k: round(v["SQ_THREAD_CYCLES_VALU"] / (64.0 * v["SQ_ACTIVE_INST_VALU"]), 4)
                                         for k, v in counters.items() if v.get("SQ_ACTIVE_INST_VALU")},
             }
+    # The CU's address / data path (texture addresser, 64 bytes per clock): what the closest-hit launches' occupancy law has as
+    # its constant term (profiles/r03c_ta_probe.txt).  TA cycles per wave-level load instruction and the
+    # load instructions per launch are measured in this run when the counter passes ran.
+    l1_path = None
+    if counters and dom in counters and counters[dom].get("TA_FLAT_READ_WAVEFRONTS_sum"):
+        c = counters[dom]
+        per_inst = c["TA_TA_BUSY_sum"] / c["TA_FLAT_READ_WAVEFRONTS_sum"]
+        ta_ms = c["TA_TA_BUSY_sum"] / CUS / CLOCK_HZ * 1e3
+        frames_seen = max(1.0, counters.get("k_resolve", {}).get("launches_seen", 3))
+        tot_busy = sum(counters[k].get("TA_TA_BUSY_sum", 0.0) * counters[k].get("launches_seen", 0) for k in counters
+                       if k in ("k_generate", "k_traverse", "k_shade", "k_resolve"))
+        l1_path = {
+            "load_instructions_per_launch": round(c.get("SQ_INSTS_VMEM_RD", c["TA_FLAT_READ_WAVEFRONTS_sum"])),
+            "ta_cycles_per_load_instruction": round(per_inst, 2),
+            "ta_time_ms_per_launch": round(ta_ms, 5),
+            "ta_share_of_serialised_launch": round(ta_ms / max(1e-9, c.get("dur_us", 0.0) / 1e3), 4) if c.get("dur_us") else None,
+            "ta_time_ms_per_frame_all_kernels": round(tot_busy / frames_seen / CUS / CLOCK_HZ * 1e3, 4),
+            "note": "TA_TA_BUSY / 256 CUs at 2.4 GHz (a lower bound on the time: the shader clock runs at ~2.2 GHz under this load); a 128-byte "
+                    "node is two 16-byte loads per lane = 2 x ~17 cycles of the CU's 64-byte-per-clock address path per wave step",
+        }
     if traffic is None:
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         try:
@@ -475,11 +497,12 @@ def main():
         latency_model = {"unavailable": "%s: %s" % (type(e).__name__, e)}
     roofline = {
         "bound": "latency",
-        "bound_note": "neither roof binds k_traverse: HBM traffic is a sixth of the algorithmic bytes (the scene stays in L2 / Infinity "
-                      "Cache) and the vector ALUs issue ~40-50 % of their rate (`valu`, at low lane use: 16 rays of a wave step in "
-                      "lockstep); what binds is the dependent chain of a node step (load -> box test -> stack -> pop -> load) times "
-                      "the steps per ray at the hardware's 8 waves x 16 rays per SIMD -- DESIGN.md section 4 has the occupancy sweep "
-                      "and the instruction-count, rays-in-flight and node-size experiments that say so; `achieved`/`peak`/`frac` are the "
+        "bound_note": "neither of the contract's roofs binds k_traverse: HBM traffic is a sixth of the algorithmic bytes (the scene stays in "
+                      "L2 / Infinity Cache).  What binds is the CU's own address / data path (`l1_path`: ~17 texture-addresser cycles per "
+                      "wave-level load, two per node step, 32 resident waves: the ~1000-cycle step) with the exposed latency of the "
+                      "dependent chain (load -> box test -> stack -> pop -> load) on top -- closest-hit time = 0.32 ms of address path + "
+                      "1.53 / (waves per SIMD) ms per frame -- and the vector ALUs right behind (`valu`: half-empty waves, 16 rays in "
+                      "lockstep).  DESIGN.md section 4 has the occupancy sweep and the load probe; `achieved`/`peak`/`frac` are the "
                       "contract's algorithmic-bytes figure against the 8 TB/s HBM roof",
         "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
@@ -499,6 +522,7 @@ def main():
         "per_frame_ms": per_frame_ms["overlapped"], "per_frame_ms_serialised": per_frame_ms["serialised"],
         "per_frame_ms_one_frame_in_flight": per_frame_ms["one_frame_in_flight"],
         "valu": valu,
+        "l1_path": l1_path,
         "latency_model": latency_model,
     }
 
