@@ -456,8 +456,11 @@ def main():
             "ta_time_ms_per_launch": round(ta_ms, 5),
             "ta_share_of_serialised_launch": round(ta_ms / max(1e-9, c.get("dur_us", 0.0) / 1e3), 4) if c.get("dur_us") else None,
             "ta_time_ms_per_frame_all_kernels": round(tot_busy / frames_seen / CUS / CLOCK_HZ * 1e3, 4),
+            "ta_share_of_the_frame_interval": round(tot_busy / frames_seen / CUS / CLOCK_HZ * 1e3 / ms_per_step, 4),
             "note": "TA_TA_BUSY / 256 CUs at 2.4 GHz (a lower bound on the time: the shader clock runs at ~2.2 GHz under this load); a 128-byte "
-                    "node is two 16-byte loads per lane = 2 x ~17 cycles of the CU's 64-byte-per-clock address path per wave step",
+                    "node is two 16-byte loads per lane = 2 x ~17 cycles of the CU's 64-byte-per-clock address path per wave step.  "
+                    "`ta_share_of_the_frame_interval` is the roof this design runs against: the address paths' time for ALL of a frame's "
+                    "loads over the frame interval of the timed region",
         }
     if traffic is None:
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
