@@ -440,7 +440,7 @@ def main():
                                         for k, v in counters.items() if v.get("SQ_ACTIVE_INST_VALU")},
             }
     # The CU's address / data path (texture addresser, 64 bytes per clock): what the closest-hit launches' occupancy law has as
-    # its constant term (profiles/r03c_ta_probe.txt).  TA cycles per wave-level load instruction and the
+    # its constant term (profiles/r03c_step_probes.txt).  TA cycles per wave-level load instruction and the
     # load instructions per launch are measured in this run when the counter passes ran.
     l1_path = None
     if counters and dom in counters and counters[dom].get("TA_FLAT_READ_WAVEFRONTS_sum"):
@@ -501,11 +501,11 @@ def main():
     roofline = {
         "bound": "latency",
         "bound_note": "neither of the contract's roofs binds k_traverse: HBM traffic is a sixth of the algorithmic bytes (the scene stays in "
-                      "L2 / Infinity Cache).  What binds is the CU's own address / data path (`l1_path`: ~17 texture-addresser cycles per "
-                      "wave-level load, two per node step, 32 resident waves: the ~1000-cycle step) with the exposed latency of the "
-                      "dependent chain (load -> box test -> stack -> pop -> load) on top -- closest-hit time = 0.32 ms of address path + "
-                      "1.53 / (waves per SIMD) ms per frame -- and the vector ALUs right behind (`valu`: half-empty waves, 16 rays in "
-                      "lockstep).  DESIGN.md section 4 has the occupancy sweep and the load probe; `achieved`/`peak`/`frac` are the "
+                      "L2 / Infinity Cache).  A node step sits at the knee of the CU's own address / data path (`l1_path`: ~17 texture-addresser "
+                      "cycles per wave-level load, two per node step; a third costs +19 %, one fewer returns nothing) and is paced by its "
+                      "dependent chain (load -> box test -> stack -> pop -> load) at the hardware's 8 waves per SIMD -- closest-hit time = "
+                      "0.32 + 1.53 / (waves per SIMD) ms per frame -- with the vector ALUs about half busy (`valu`: half-empty waves, 16 "
+                      "rays in lockstep).  DESIGN.md section 4 has the occupancy sweep and the three probes; `achieved`/`peak`/`frac` are the "
                       "contract's algorithmic-bytes figure against the 8 TB/s HBM roof",
         "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
