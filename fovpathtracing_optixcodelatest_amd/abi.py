@@ -9,7 +9,7 @@ FOVPT_OK = 0
 MATERIAL_FLAG_SHADOW_CATCHER = 1
 OPT_SKY_MISS, OPT_RUSSIAN_ROULETTE = 1, 2      # fovpt_config.options (include/fovpt.h)
 
-OP_SIN, OP_COS, OP_ACOS, OP_ATAN2, OP_LOG, OP_POW, OP_SQRT, OP_DIV, OP_RSQRTD, OP_UNORM8 = range(1, 11)
+OP_SIN, OP_COS, OP_ACOS, OP_ATAN2, OP_LOG, OP_POW, OP_SQRT, OP_DIV, OP_RSQRTD, OP_UNORM8, OP_HALFPLUS = range(1, 12)
 
 
 class Float3(C.Structure):

@@ -216,13 +216,19 @@ __device__ inline void probe_sample(const fovpt_probe& pr, const uint32_t* __res
 // ------------------------------------------------------------------------------------------
 typedef fovpt_material Mat;
 
+// The reference writes 1.0 / sqrtf(x) and 0.5 + y with binary64 literals: a binary64 operation on binary32 values, rounded back to
+// binary32.  That equals the correctly rounded binary32 operation (rounding twice is innocuous for + - * / sqrt when the wide format
+// has at least 2 * 24 + 2 significant bits), which is how the compiler emits them: no binary64 instruction comes from these lines
+// (the 231 of k_shade are the polynomial cores of include/fovpt_detmath.h).  FOVPT_OP_RSQRTD / _HALFPLUS check the device's result
+// against the oracle's binary64 expression over every binade (tests/test_gpu_parity.py).
+__device__ inline float rcp_of_sqrt_as_the_reference(float x) { return (float)(1.0 / (double)sqrtf(x)); }
 __device__ inline void basis_from_vector(const V3& w, V3& u, V3& v)          // maths.h:94-108
 {
     if (fabsf(w.x) > fabsf(w.y)) {
-        float invLen = (float)(1.0 / (double)sqrtf(w.x * w.x + w.z * w.z));
+        float invLen = rcp_of_sqrt_as_the_reference(w.x * w.x + w.z * w.z);
         u = v3(-w.z * invLen, 0.0f, w.x * invLen);
     } else {
-        float invLen = (float)(1.0 / (double)sqrtf(w.y * w.y + w.z * w.z));
+        float invLen = rcp_of_sqrt_as_the_reference(w.y * w.y + w.z * w.z);
         u = v3(0.0f, w.z * invLen, -w.y * invLen);
     }
     v = cross(w, u);
@@ -230,9 +236,10 @@ __device__ inline void basis_from_vector(const V3& w, V3& u, V3& v)          // 
 __device__ inline V3 safe_normalize(const V3& a)                              // maths.h:144-156
 {
     float m = dot(a, a);
-    if ((double)m > 0.0) return a * (float)(1.0 / (double)sqrtf(m));
+    if ((double)m > 0.0) return a * rcp_of_sqrt_as_the_reference(m);
     return v3(0.0f);
 }
+__device__ inline float half_plus_as_the_reference(float y) { return (float)(0.5 + (double)y); }      // (see rcp_of_sqrt_as_the_reference)
 __device__ inline float schlick(float u)                                      // Disney.cuh:51-56
 {
     float m = clampf(1 - u, 0.0f, 1.0f);
@@ -421,7 +428,7 @@ __device__ V3 bsdf_eval(const Mat& mat, const V3& albedo, const BsdfView& w, con
             float FH = schlick(LDotH);
             V3 Fs = lerp3(Cspec0, v3(1.f), FH);
             float FL = schlick(NDotL), FV = w.FV;
-            float Fd90 = (float)(0.5 + (double)(2.0f * LDotH * LDotH * mat.roughness));
+            float Fd90 = half_plus_as_the_reference(2.0f * LDotH * LDotH * mat.roughness);     // Disney.cuh: 0.5 + (binary32 product), in binary64
             float Fd = lerpf(1.0f, Fd90, FL) * lerpf(1.0f, Fd90, FV);
             float Dr = gtr1_pre(NDotH, w.cc_a2, w.cc_log);
             float Fc = lerpf(.04f, 1.0f, FH);
@@ -1789,7 +1796,8 @@ __global__ void k_math(int op, const float* a, const float* b, float* out, size_
     case FOVPT_OP_POW: r = fovpt_dm_powf(a[i], b[i]); break;
     case FOVPT_OP_SQRT: r = sqrtf(a[i]); break;
     case FOVPT_OP_DIV: r = a[i] / b[i]; break;
-    case FOVPT_OP_RSQRTD: r = (float)(1.0 / (double)sqrtf(a[i])); break;
+    case FOVPT_OP_RSQRTD: r = rcp_of_sqrt_as_the_reference(a[i]); break;
+    case FOVPT_OP_HALFPLUS: r = half_plus_as_the_reference(a[i]); break;
     case FOVPT_OP_UNORM8: r = unorm8((uint32_t)a[i] & 255u); break;
     }
     out[i] = r;

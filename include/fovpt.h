@@ -375,6 +375,7 @@ void fovpt_image_free(fovpt_float4* texels);
 #define FOVPT_OP_DIV    8
 #define FOVPT_OP_RSQRTD 9   /* (float)(1.0 / (double)sqrtf(a)), maths.h:98 */
 #define FOVPT_OP_UNORM8 10  /* texel channel (uint8)a / 255.0f as the shading kernel computes it */
+#define FOVPT_OP_HALFPLUS 11 /* (float)(0.5 + (double)a), Disney.cuh Fd90 */
 int fovpt_debug_math(fovpt_ctx* ctx, int op, const float* a, const float* b, float* out, size_t n);
 /* tests only: the production traversal kernel on a batch of n rays (host arrays, 3 floats per origin / direction): closest
  * hit -> global primitive id (0xffffffff = miss) and (t, u, v); occlusion ray (deviceProgram.cu:224-248) -> 0 / 1.

@@ -1342,6 +1342,7 @@ void orc_math(int op, size_t n, const float* a, const float* b, float* out)
         case FOVPT_OP_SQRT: out[i] = sqrtf(a[i]); break;
         case FOVPT_OP_DIV: out[i] = a[i] / b[i]; break;
         case FOVPT_OP_RSQRTD: out[i] = (float)(1.0 / (double)sqrtf(a[i])); break;
+        case FOVPT_OP_HALFPLUS: out[i] = (float)(0.5 + (double)a[i]); break;
         default: out[i] = 0.0f;
         }
     }

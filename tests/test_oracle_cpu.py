@@ -713,3 +713,27 @@ def test_opt_in_extensions_behave(oracle):
     assert rays["rr"] < 0.9 * rays["plain"]
     assert abs(means["rr"] - means["plain"]) < 0.03 * means["plain"]
     assert means["sky"] > means["plain"] * 1.001
+
+
+def test_binary64_detours_of_the_reference_equal_their_binary32_forms(oracle):
+    """maths.h writes 1.0 / sqrtf(x) and Disney.cuh 0.5 + y with binary64 literals: a binary64 operation on binary32 values,
+    rounded back.  The compiler emits the binary32 operation for them in the HIP kernels (wavefront.hip: rounding twice is
+    innocuous for + - * / when the wide format has >= 2 * 24 + 2 bits).  Here on the CPU: every binade, random significands, the range ends."""
+    rng = np.random.default_rng(7)
+    e = rng.integers(-126, 128, 400000)
+    m = rng.integers(0, 1 << 23, 400000).astype(np.float64) / (1 << 23) + 1.0
+    x = np.concatenate([np.ldexp(m, e).astype(np.float32), np.float32([np.finfo(np.float32).tiny, np.finfo(np.float32).max, 1.0, 2.0, 3.0])])
+    s = np.sqrt(x)                                                           # binary32, correctly rounded (sqrtf)
+    with np.errstate(over="ignore", divide="ignore"):
+        wide = (1.0 / s.astype(np.float64)).astype(np.float32)
+        narrow = np.float32(1.0) / s
+    assert np.array_equal(wide.view(np.uint32), narrow.view(np.uint32))
+    e = rng.integers(-149, 128, 400000)
+    y = np.ldexp(m, e).astype(np.float32)
+    y = np.concatenate([y, -y, np.float32([0.0, -0.5, 0.5, 2.0 ** -25, -(2.0 ** -25), 0.5 - 2.0 ** -25])])
+    with np.errstate(over="ignore"):
+        wide = (0.5 + y.astype(np.float64)).astype(np.float32)
+        narrow = np.float32(0.5) + y
+    assert np.array_equal(wide.view(np.uint32), narrow.view(np.uint32))
+    assert np.array_equal(oracle.math_op(11, y).view(np.uint32), narrow.view(np.uint32))          # FOVPT_OP_HALFPLUS in the oracle
+    assert np.array_equal(oracle.math_op(9, x).view(np.uint32), (np.float32(1.0) / np.sqrt(x)).view(np.uint32))   # FOVPT_OP_RSQRTD
