@@ -366,6 +366,31 @@ def main():
         r.render_async()
         r.synchronize()
     frame_latency_ms = (time.perf_counter() - t0) / lat_frames * 1e3
+    # ... and the same two figures with fovpt_config.chains_per_frame = 2: every frame rendered as two independent chains over
+    # halves of its sample slots, frames issued one at a time -- the throughput of two frames in flight at the latency of one
+    two_chains = None
+    if world == 1:
+        cfg.chains_per_frame = 2
+        r.config = cfg
+        for _ in range(5):
+            r.launchParams.frame.subframe_index = 0
+            r.render_async()
+        r.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(lat_frames):
+            r.launchParams.frame.subframe_index = 0
+            r.render_async()
+            r.synchronize()
+        lat2 = (time.perf_counter() - t0) / lat_frames * 1e3
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            r.launchParams.frame.subframe_index = 0
+            r.render_async()
+        r.synchronize()
+        two_chains = {"ms_per_step": round((time.perf_counter() - t0) / args.steps * 1e3, 4), "frame_latency_ms": round(lat2, 4),
+                      "note": "fovpt_config.chains_per_frame = 2 (never `value`): frames back to back / one frame alone"}
+        cfg.chains_per_frame = 0
+        r.config = cfg
 
     # ---- per-kernel device time, HIP events on the library's own streams around every kernel (fovpt_stats): once as the
     # frame really runs (two streams, frames back to back: kernels overlap) and once with every kernel ALONE (profile 2)
@@ -533,6 +558,7 @@ def main():
         "metric": "Mray/s", "value": round(mrays, 2), "unit": "Mray/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "frame_latency_ms": round(frame_latency_ms, 4),
+        "two_chains_per_frame": two_chains,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {

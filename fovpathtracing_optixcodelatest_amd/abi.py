@@ -148,6 +148,7 @@ class Config(C.Structure):
         ("rank", C.c_int32), ("world", C.c_int32), ("tile_w", C.c_int32), ("tile_h", C.c_int32),
         ("profile", C.c_int32), ("write_guides", C.c_int32), ("options", C.c_int32),
         ("frames_in_flight", C.c_int32),      # 0 = library default (2), 1, 2
+        ("chains_per_frame", C.c_int32),      # 0 / 1 = one chain per frame, 2 = two (for callers that synchronise every frame)
     ]
 
     @classmethod

@@ -56,6 +56,9 @@ struct StateSet {
     DevBuf sq_o[FOVPT_NSQ], sq_d[FOVPT_NSQ], sq_vis[FOVPT_NSQ], sq_occ[FOVPT_NSQ];   // shadow queues, one per bounce in flight
     hipEvent_t ev_shade[FOVPT_MAX_ITERS + 1] = {};
     hipEvent_t ev_shadow[FOVPT_MAX_ITERS + 1] = {};
+    hipEvent_t ev_shade2[FOVPT_MAX_ITERS + 1] = {};     // the same for the second chain of a frame (fovpt_config.chains_per_frame = 2)
+    hipEvent_t ev_shadow2[FOVPT_MAX_ITERS + 1] = {};
+    hipEvent_t ev_last_closest2 = nullptr;
     hipEvent_t ev_done = nullptr;          // recorded after the resolve of the last job that used this set
     hipEvent_t ev_last_closest = nullptr;  // completion of the job's last closest-hit launch (the last shading launch may run on the shadow stream)
     bool used = false;
@@ -83,6 +86,7 @@ struct fovpt_ctx {
     // previous job's), and `shadow_stream` remains the one stream every finished frame is ordered on (fovpt_stream()).
     hipStream_t lane_main[FOVPT_MAX_LANES] = {}, lane_shadow[FOVPT_MAX_LANES] = {};   // [0] = stream / shadow_stream
     int lanes = FOVPT_LANES_DEFAULT;
+    int chains_default = 1;                // what fovpt_config.chains_per_frame = 0 means (FOVPT_CHAINS)
     std::string err;
     fovpt_config cfg;
     // scene
@@ -250,6 +254,7 @@ int ensure_state(fovpt_ctx* c, StateSet& S, size_t slots, size_t launches, hipSt
     if (!S.counters.p) {
         HIPCHK(c, S.counters.reserve(sizeof(Counters)));
         HIPCHK(c, hipMemsetAsync(S.counters.p, 0, sizeof(Counters), st));      // (the main stream of the job that is about to use the set)
+        HIPCHK(c, hipStreamSynchronize(st));                                   // once per set: a second chain starts on another stream
     }
     return FOVPT_OK;
 }
@@ -381,11 +386,16 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     // shadow_stream, so they all run on lane 0 (as before round 3)
     const int fif = c->cfg.frames_in_flight > 0 ? c->cfg.frames_in_flight : c->lanes;
     const unsigned lanes = (unsigned)(fif < c->lanes ? fif : c->lanes);
-    const unsigned lane = (lanes > 1u && !chunked) ? c->jobs % lanes : 0u;
+    // chains_per_frame = 2: the job is TWO chains -- the halves of its sample slots, each with four of the eight queue shards, on
+    // the two lanes -- and one resolve behind both.  (Not for chunk jobs, nor for jobs too small to split.)
+    const int chains = c->cfg.chains_per_frame > 0 ? c->cfg.chains_per_frame : c->chains_default;
+    const bool two_chains = chains == 2 && c->lanes >= 2 && !chunked && slots >= 16384;
+    const unsigned lane = two_chains ? 0u : (lanes > 1u && !chunked) ? c->jobs % lanes : 0u;
     hipStream_t st = c->lane_main[lane], ss = c->lane_shadow[lane];
     // the set is free once the resolve of the job that used it last has run (reserve() may also free and
     // reallocate its buffers, which the runtime orders after all device work)
     if (S.used) HIPCHK(c, hipStreamWaitEvent(st, S.ev_done, 0));
+    if (S.used && two_chains) HIPCHK(c, hipStreamWaitEvent(c->lane_main[1], S.ev_done, 0));
     int rc = ensure_state(c, S, (size_t)slots, (size_t)launches, st);
     if (rc) return rc;
     c->jobs++;
@@ -411,21 +421,16 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     sc.num_tris = c->num_tris; sc.any_catcher = c->any_catcher;
     sc.tri_off = (uint32_t)((const char*)c->tris - (const char*)c->nodes);
     Counters* cnt = (Counters*)S.counters.p;
-    RayQueue qa, qb;
-    qa.o = (float4*)S.q_o[0].p; qa.d = (float4*)S.q_d[0].p;
-    qb.o = (float4*)S.q_o[1].p; qb.d = (float4*)S.q_d[1].p;
-
     // (the queue counters are zero: at allocation, and again by the resolve of the set's previous job)
 #if FOVPT_V_STEPSTAT
     HIPCHK(c, hipMemsetAsync(cnt, 0, offsetof(Counters, stat_radiance), st));      // the diagnostic build keeps them after the job
 #endif
-    const int grid = c->grid;
     const uint32_t cap = shard_capacity((size_t)slots);
-    { Timed t(c, 0, st); fovpt_launch_generate(st, fd, ps, qa, cap, cnt, (uint32_t)slots, grid); }
     // iterations: depth 0 .. max_depth-1, plus the reference's discarded segment and shadow-catcher
     // pass-throughs (which do not advance depth) when the scene holds a catcher
     int iters = c->cfg.max_depth + (c->any_catcher ? 1 + 24 : 0);
     if (iters > FOVPT_MAX_ITERS) iters = FOVPT_MAX_ITERS;
+    const int nsq = iters < FOVPT_NSQ ? iters : FOVPT_NSQ;        // (only that many shadow queue buffers are allocated)
     // Main chain (stream `st`):    generate, closest(0), shade(0), closest(1), shade(1), ... shade(D-1)
     // Shadow chain (stream `ss`):  occlusion(it) as soon as shade(it) has queued its rays; then resolve.
     // Every radiance cell has one writer, so the only joins are: shade(it+2) reuses the shadow queue
@@ -435,28 +440,49 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     // async_last_shade it runs on the shadow stream, in front of the last occlusion launch and the resolve, so the main stream
     // is free for the next job's generate and camera rays one shading launch earlier.
     const bool tail_async = c->async_last_shade != 0;
-    { Timed t(c, 1, st); fovpt_launch_traverse(st, sc, ps, qa, sq[0], cap, cnt, 0, -1, c->grid_trace, (tail_async && iters == 1) ? S.ev_last_closest : nullptr); }
-    const int nsq = iters < FOVPT_NSQ ? iters : FOVPT_NSQ;        // (only that many buffers are allocated)
-    for (int it = 0; it < iters; it++) {
-        const bool last = it + 1 == iters;
-        if (last && tail_async) {
-            HIPCHK(c, hipStreamWaitEvent(ss, S.ev_last_closest, 0));      // (the shadow queue it writes was read by occlusion(it - nsq): earlier on this stream)
-            { Timed t(c, 2, ss); fovpt_launch_shade(ss, fd, sc, ps, qa, qb, sq[it % nsq], cap, cnt, it, c->grid_shade); }
-        } else {
-            if (it >= nsq) HIPCHK(c, hipStreamWaitEvent(st, S.ev_shadow[it - nsq], 0));
-            // the events ride on the kernels' own completion signals (hipExtLaunchKernel): a separate
-            // hipEventRecord would put a marker packet between shade(it) and closest(it+1), ~6 us on the critical path
-            { Timed t(c, 2, st); fovpt_launch_shade(st, fd, sc, ps, qa, qb, sq[it % nsq], cap, cnt, it, c->grid_shade, S.ev_shade[it]); }
-            HIPCHK(c, hipStreamWaitEvent(ss, S.ev_shade[it], 0));
+    // One chain: the sample slots [slot_begin, slot_end) through the queue shards of `sel` (0: all eight; 1 / 2: one half), with
+    // 1 / div of the usual grids.
+    auto issue_chain = [&](hipStream_t st, hipStream_t ss, uint32_t sel, uint32_t slot_begin, uint32_t slot_end, int div,
+                           hipEvent_t* ev_shade, hipEvent_t* ev_shadow, hipEvent_t ev_last_closest) -> int {
+        RayQueue qa, qb;
+        qa.o = (float4*)S.q_o[0].p; qa.d = (float4*)S.q_d[0].p;
+        qb.o = (float4*)S.q_o[1].p; qb.d = (float4*)S.q_d[1].p;
+        const int g_gen = c->grid / div, g_trace = c->grid_trace / div, g_shadow = c->grid_shadow / div, g_shade = c->grid_shade / div;
+        { Timed t(c, 0, st); fovpt_launch_generate(st, fd, ps, qa, cap, cnt, slot_begin, slot_end, g_gen, sel); }
+        { Timed t(c, 1, st); fovpt_launch_traverse(st, sc, ps, qa, sq[0], cap, cnt, 0, -1, g_trace, (tail_async && iters == 1) ? ev_last_closest : nullptr, sel); }
+        for (int it = 0; it < iters; it++) {
+            const bool last = it + 1 == iters;
+            if (last && tail_async) {
+                HIPCHK(c, hipStreamWaitEvent(ss, ev_last_closest, 0));      // (the shadow queue it writes was read by occlusion(it - nsq): earlier on this stream)
+                { Timed t(c, 2, ss); fovpt_launch_shade(ss, fd, sc, ps, qa, qb, sq[it % nsq], cap, cnt, it, g_shade, nullptr, sel); }
+            } else {
+                if (it >= nsq) HIPCHK(c, hipStreamWaitEvent(st, ev_shadow[it - nsq], 0));
+                // the events ride on the kernels' own completion signals (hipExtLaunchKernel): a separate
+                // hipEventRecord would put a marker packet between shade(it) and closest(it+1), ~6 us on the critical path
+                { Timed t(c, 2, st); fovpt_launch_shade(st, fd, sc, ps, qa, qb, sq[it % nsq], cap, cnt, it, g_shade, ev_shade[it], sel); }
+                HIPCHK(c, hipStreamWaitEvent(ss, ev_shade[it], 0));
+            }
+            { Timed t(c, 3, ss); fovpt_launch_traverse(ss, sc, ps, qb, sq[it % nsq], cap, cnt, -1, it, g_shadow, ev_shadow[it], sel); }
+            if (!last) { Timed t(c, 1, st); fovpt_launch_traverse(st, sc, ps, qb, sq[0], cap, cnt, it + 1, -1, g_trace, (tail_async && it + 2 == iters) ? ev_last_closest : nullptr, sel); }
+            const RayQueue tmp = qa; qa = qb; qb = tmp;
         }
-        { Timed t(c, 3, ss); fovpt_launch_traverse(ss, sc, ps, qb, sq[it % nsq], cap, cnt, -1, it, c->grid_shadow, S.ev_shadow[it]); }
-        if (!last) { Timed t(c, 1, st); fovpt_launch_traverse(st, sc, ps, qb, sq[0], cap, cnt, it + 1, -1, c->grid_trace, (tail_async && it + 2 == iters) ? S.ev_last_closest : nullptr); }
-        const RayQueue tmp = qa; qa = qb; qb = tmp;
+        return FOVPT_OK;
+    };
+    if (two_chains) {
+        const uint32_t half = (uint32_t)(slots / 2 / FOVPT_BLOCK * FOVPT_BLOCK);      // (a whole number of 256-slot block iterations)
+        rc = issue_chain(c->lane_main[0], c->lane_shadow[0], 1u, 0u, half, 2, S.ev_shade, S.ev_shadow, S.ev_last_closest);
+        if (rc) return rc;
+        rc = issue_chain(c->lane_main[1], c->lane_shadow[1], 2u, half, (uint32_t)slots, 2, S.ev_shade2, S.ev_shadow2, S.ev_last_closest2);
+        if (rc) return rc;
+        HIPCHK(c, hipStreamWaitEvent(c->shadow_stream, S.ev_shadow2[iters - 1], 0));      // (the first chain's last occlusion launch IS on shadow_stream)
+    } else {
+        rc = issue_chain(st, ss, 0u, 0u, (uint32_t)slots, 1, S.ev_shade, S.ev_shadow, S.ev_last_closest);
+        if (rc) return rc;
+        // Every resolve runs on shadow_stream, whatever the lane: in job order (a later job's pixels overwrite, or blend with, an
+        // earlier one's), behind whatever the caller has queued on fovpt_stream() since the previous frame, and in front of what it
+        // queues next.  A job of the second lane joins it behind its last occlusion launch (which waited for its last shade).
+        if (ss != c->shadow_stream) HIPCHK(c, hipStreamWaitEvent(c->shadow_stream, S.ev_shadow[iters - 1], 0));
     }
-    // Every resolve runs on shadow_stream, whatever the lane: in job order (a later job's pixels overwrite, or blend with, an
-    // earlier one's), behind whatever the caller has queued on fovpt_stream() since the previous frame, and in front of what it
-    // queues next.  A job of the second lane joins it behind its last occlusion launch (which waited for its last shade).
-    if (ss != c->shadow_stream) HIPCHK(c, hipStreamWaitEvent(c->shadow_stream, S.ev_shadow[iters - 1], 0));
     { Timed t(c, 4, c->shadow_stream); fovpt_launch_resolve(c->shadow_stream, fd, ps, cnt, S.ev_done); }
     HIPCHK(c, hipGetLastError());
     return FOVPT_OK;
@@ -570,6 +596,7 @@ int fovpt_create(fovpt_ctx** out, int device)
     e = hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_hi);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->shadow_stream, hipStreamDefault, prio_lo);
     if (const char* l = getenv("FOVPT_LANES")) { const int v = atoi(l); if (v >= 1 && v <= FOVPT_MAX_LANES) c->lanes = v; }
+    if (const char* l = getenv("FOVPT_CHAINS")) { const int v = atoi(l); if (v == 1 || v == 2) c->chains_default = v; }
     c->nsets = c->lanes < 2 ? 2u : (unsigned)c->lanes;
     c->lane_main[0] = c->stream; c->lane_shadow[0] = c->shadow_stream;
     for (int l = 1; l < c->lanes; l++) {
@@ -580,9 +607,12 @@ int fovpt_create(fovpt_ctx** out, int device)
         for (int k = 0; k <= FOVPT_MAX_ITERS && e == hipSuccess; k++) {
             e = hipEventCreateWithFlags(&S.ev_shade[k], hipEventDefault);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&S.ev_shadow[k], hipEventDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&S.ev_shade2[k], hipEventDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&S.ev_shadow2[k], hipEventDefault);
         }
         if (e == hipSuccess) e = hipEventCreateWithFlags(&S.ev_done, hipEventDefault);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&S.ev_last_closest, hipEventDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&S.ev_last_closest2, hipEventDefault);
     }
     if (e != hipSuccess) { fovpt_destroy(c); return fail(nullptr, FOVPT_E_DEVICE, "stream/event creation: %s", hipGetErrorString(e)); }
     *out = c;
@@ -600,9 +630,12 @@ void fovpt_destroy(fovpt_ctx* c)
         for (int k = 0; k <= FOVPT_MAX_ITERS; k++) {
             if (S.ev_shade[k]) (void)hipEventDestroy(S.ev_shade[k]);
             if (S.ev_shadow[k]) (void)hipEventDestroy(S.ev_shadow[k]);
+            if (S.ev_shade2[k]) (void)hipEventDestroy(S.ev_shade2[k]);
+            if (S.ev_shadow2[k]) (void)hipEventDestroy(S.ev_shadow2[k]);
         }
         if (S.ev_done) (void)hipEventDestroy(S.ev_done);
         if (S.ev_last_closest) (void)hipEventDestroy(S.ev_last_closest);
+        if (S.ev_last_closest2) (void)hipEventDestroy(S.ev_last_closest2);
         for (DevBuf* b : S.all()) b->release();
     }
     (void)fovpt_comm_destroy(c);
@@ -876,6 +909,7 @@ int fovpt_set_config(fovpt_ctx* c, const fovpt_config* cfg)
     if (cfg->spp_periphery < 1 || cfg->spp_middle < 1 || cfg->spp_fovea < 1 || cfg->spp_uniform < 1) return fail(c, FOVPT_E_INVALID, "spp must be >= 1");
     if (cfg->r_inner < 0 || cfg->r_outer < cfg->r_inner) return fail(c, FOVPT_E_INVALID, "bad radii");
     if (cfg->frames_in_flight < 0 || cfg->frames_in_flight > FOVPT_MAX_LANES) return fail(c, FOVPT_E_INVALID, "frames_in_flight must be 0 (default), 1 or 2");
+    if (cfg->chains_per_frame < 0 || cfg->chains_per_frame > 2) return fail(c, FOVPT_E_INVALID, "chains_per_frame must be 0, 1 or 2");
     if (cfg->options & ~(FOVPT_OPT_SKY_MISS | FOVPT_OPT_RUSSIAN_ROULETTE)) return fail(c, FOVPT_E_INVALID, "unknown option bits %d", cfg->options);
     c->cfg = *cfg;
     return FOVPT_OK;

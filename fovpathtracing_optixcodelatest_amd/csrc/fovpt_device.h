@@ -207,13 +207,15 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
                             BvhBuildResult* out, char* err, size_t errlen);
 
 // cap = shard capacity (in items) of the radiance queues and of the shadow queue.
-void fovpt_launch_generate(hipStream_t st, const FrameDev& fd, PathState ps, RayQueue queue0, uint32_t cap, Counters* cnt, uint32_t total_slots, int grid);
+// sel: 0 = all eight queue shards (a whole job); 1 / 2 = the first / second four (one of the two chains of a frame)
+void fovpt_launch_generate(hipStream_t st, const FrameDev& fd, PathState ps, RayQueue queue0, uint32_t cap, Counters* cnt, uint32_t slot_begin,
+                           uint32_t slot_end, int grid, uint32_t sel = 0);
 // One launch that traces the shadow queue of iteration it_shadow (if >= 0) and the radiance queue of
 // iteration it_closest (if >= 0).
 void fovpt_launch_traverse(hipStream_t st, SceneView sc, PathState ps, RayQueue queue, ShadowQueue sq, uint32_t cap,
-                           Counters* cnt, int it_closest, int it_shadow, int grid, hipEvent_t done = nullptr);
+                           Counters* cnt, int it_closest, int it_shadow, int grid, hipEvent_t done = nullptr, uint32_t sel = 0);
 void fovpt_launch_shade(hipStream_t st, const FrameDev& fd, SceneView sc, PathState ps, RayQueue queue_in, RayQueue queue_out,
-                        ShadowQueue sq, uint32_t cap, Counters* cnt, int depth, int grid, hipEvent_t done = nullptr);
+                        ShadowQueue sq, uint32_t cap, Counters* cnt, int depth, int grid, hipEvent_t done = nullptr, uint32_t sel = 0);
 void fovpt_launch_resolve(hipStream_t st, const FrameDev& fd, PathState ps, Counters* cnt, hipEvent_t done = nullptr);
 // multi-GPU gather plan (see wavefront.hip): owner map + per-block counts; scan (phase 0) / fill (phase 1); pack; unpack
 void fovpt_launch_plan_owner(hipStream_t st, const FrameDev& fd, uint8_t* owner, uint32_t* block_count, uint32_t nblocks);

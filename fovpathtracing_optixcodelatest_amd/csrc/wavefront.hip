@@ -447,7 +447,13 @@ __device__ V3 bsdf_eval(const Mat& mat, const V3& albedo, const BsdfView& w, con
 // Ballot compaction into a sharded queue.  Lanes with pred get distinct positions inside shard
 // blockIdx % 8: wave ballot + popcount prefix, the four wave totals meet in LDS, and ONE atomic per
 // block-iteration reserves the range.  Must be called by all 256 threads of the block (two barriers).
-__device__ inline uint32_t block_append(Counters* cnt, int word, uint32_t cap, bool pred, uint32_t* s_scratch /* [6] */)
+// Shard selection of a launch: 0 = all eight shards; 1 / 2 = the first / second four -- the two CHAINS of a frame that is rendered
+// as two independent halves (fovpt_config.chains_per_frame = 2, fovpt_api.hip): each chain's kernels read and append only inside
+// their own four shards of the same queue buffers.
+__device__ inline uint32_t sel_first(uint32_t sel) { return sel == 2u ? 4u : 0u; }
+__device__ inline uint32_t sel_mask(uint32_t sel) { return sel == 0u ? (uint32_t)FOVPT_SHARDS - 1u : 3u; }
+
+__device__ inline uint32_t block_append(Counters* cnt, int word, uint32_t cap, bool pred, uint32_t* s_scratch /* [6] */, uint32_t sel = 0u)
 {
     const unsigned long long mask = __ballot(pred);
     const uint32_t lane = __lane_id();
@@ -456,7 +462,7 @@ __device__ inline uint32_t block_append(Counters* cnt, int word, uint32_t cap, b
     if (lane == 0) s_scratch[wave] = (uint32_t)__popcll(mask);
     __syncthreads();
     const uint32_t c0 = s_scratch[0], c1 = s_scratch[1], c2 = s_scratch[2], c3 = s_scratch[3];
-    const uint32_t shard = blockIdx.x & (FOVPT_SHARDS - 1);
+    const uint32_t shard = sel_first(sel) + (blockIdx.x & sel_mask(sel));
     if (threadIdx.x == 0) {
         const uint32_t total = c0 + c1 + c2 + c3;
         s_scratch[4] = total ? atomicAdd(&cnt->shard[shard][word], total) : 0u;
@@ -470,7 +476,7 @@ __device__ inline uint32_t block_append(Counters* cnt, int word, uint32_t cap, b
 
 // Two appends at once (shadow queue and next radiance queue) behind ONE pair of barriers.
 __device__ inline void block_append2(Counters* cnt, int word_a, bool pred_a, int word_b, bool pred_b, uint32_t cap,
-                                     uint32_t* s_scratch /* [10] */, uint32_t& pos_a, uint32_t& pos_b)
+                                     uint32_t* s_scratch /* [10] */, uint32_t& pos_a, uint32_t& pos_b, uint32_t sel = 0u)
 {
     const unsigned long long ma = __ballot(pred_a), mb = __ballot(pred_b);
     const uint32_t lane = __lane_id();
@@ -481,7 +487,7 @@ __device__ inline void block_append2(Counters* cnt, int word_a, bool pred_a, int
     __syncthreads();
     const uint32_t a0 = s_scratch[0], a1 = s_scratch[1], a2 = s_scratch[2], a3 = s_scratch[3];
     const uint32_t b0 = s_scratch[4], b1 = s_scratch[5], b2 = s_scratch[6], b3 = s_scratch[7];
-    const uint32_t shard = blockIdx.x & (FOVPT_SHARDS - 1);
+    const uint32_t shard = sel_first(sel) + (blockIdx.x & sel_mask(sel));
     if (threadIdx.x == 0) {
         const uint32_t ta = a0 + a1 + a2 + a3;
         s_scratch[8] = ta ? atomicAdd(&cnt->shard[shard][word_a], ta) : 0u;
@@ -498,11 +504,15 @@ __device__ inline void block_append2(Counters* cnt, int word_a, bool pred_a, int
 
 // logical index -> physical index of a sharded queue (all in scalar registers, no indexing)
 struct ShardMap {
-    uint32_t p1, p2, p3, p4, p5, p6, p7, p8;     // exclusive prefix sums of the 8 shard counts (p0 = 0)
-    __device__ inline void load(const Counters* cnt, int word)
+    uint32_t p1, p2, p3, p4, p5, p6, p7, p8;     // exclusive prefix sums of the shard counts (p0 = 0)
+    uint32_t first_cap;                          // physical offset of the first shard of the selection (0, or 4 * cap for the second chain)
+    __device__ inline void load(const Counters* cnt, int word, uint32_t sel = 0u, uint32_t cap = 0u)
     {
-        p1 = cnt->shard[0][word]; p2 = p1 + cnt->shard[1][word]; p3 = p2 + cnt->shard[2][word]; p4 = p3 + cnt->shard[3][word];
-        p5 = p4 + cnt->shard[4][word]; p6 = p5 + cnt->shard[5][word]; p7 = p6 + cnt->shard[6][word]; p8 = p7 + cnt->shard[7][word];
+        const uint32_t f = sel_first(sel);
+        first_cap = f * cap;
+        p1 = cnt->shard[f][word]; p2 = p1 + cnt->shard[f + 1][word]; p3 = p2 + cnt->shard[f + 2][word]; p4 = p3 + cnt->shard[f + 3][word];
+        if (sel == 0u) { p5 = p4 + cnt->shard[4][word]; p6 = p5 + cnt->shard[5][word]; p7 = p6 + cnt->shard[6][word]; p8 = p7 + cnt->shard[7][word]; }
+        else p5 = p6 = p7 = p8 = p4;             // a chain's four shards: no index reaches the other four
     }
     __device__ inline uint32_t total() const { return p8; }
     __device__ inline uint32_t phys(uint32_t i, uint32_t cap) const
@@ -515,7 +525,7 @@ struct ShardMap {
         if (i >= p5) { s = 5; base = p5; }
         if (i >= p6) { s = 6; base = p6; }
         if (i >= p7) { s = 7; base = p7; }
-        return s * cap + (i - base);
+        return first_cap + s * cap + (i - base);
     }
     // the same for lane index i of 16 consecutive indices starting at the wave-uniform i0: the shard is
     // found with scalar instructions unless the 16 straddle a shard boundary
@@ -529,7 +539,7 @@ struct ShardMap {
         if (i0 >= p5) { s = 5; base = p5; next = p6; }
         if (i0 >= p6) { s = 6; base = p6; next = p7; }
         if (i0 >= p7) { s = 7; base = p7; next = 0xffffffffu; }
-        if (i0 + 15u < next) return s * cap - base + i;
+        if (i0 + 15u < next) return first_cap + s * cap - base + i;
         return phys(i, cap);
     }
 };
@@ -555,10 +565,11 @@ __device__ inline bool ring_alive(const FrameDev& fd, const PassDev& P, uint32_t
 
 // ---- generate ----------------------------------------------------------------------------
 __global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, PathState ps, RayQueue queue0, uint32_t cap,
-                                                          Counters* __restrict__ cnt, uint32_t total_slots)
+                                                          Counters* __restrict__ cnt, uint32_t slot_begin, uint32_t total_slots, uint32_t sel)
 {
+    // slots [slot_begin, total_slots) into the shards of `sel` (a whole job: 0 .. all slots, all shards; a chain: its half)
     __shared__ uint32_t s_scratch[6];
-    for (uint32_t base = blockIdx.x * FOVPT_BLOCK; base < total_slots; base += gridDim.x * FOVPT_BLOCK) {
+    for (uint32_t base = slot_begin + blockIdx.x * FOVPT_BLOCK; base < total_slots; base += gridDim.x * FOVPT_BLOCK) {
         const uint32_t slot = base + threadIdx.x;
         bool live = slot < total_slots;
         int p = 0;
@@ -600,7 +611,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, Pat
                 ps.backplate[P.launch_base + (ly - P.row0) * P.gw + lx] = probe_eval(fd.probe, fd.probe_row_mul, u, v);
             }
         }
-        const uint32_t pos = block_append(cnt, FOVPT_CNT_Q(0), cap, live, s_scratch);
+        const uint32_t pos = block_append(cnt, FOVPT_CNT_Q(0), cap, live, s_scratch, sel);
         if (live) {
             queue0.o[pos] = make_float4(fd.eye[0], fd.eye[1], fd.eye[2], __uint_as_float(slot));
             queue0.d[pos] = f4(ray_dir, 0.f);
@@ -1008,14 +1019,14 @@ __device__ inline void traverse_shadow_pool(const SceneView& sc, const PathState
 // closest-hit launch neither fetches the occlusion queue's shard sizes before it starts nor carries that loop's registers.)
 template <int MODE>
 __global__ __launch_bounds__(FOVPT_TBLOCK, FOVPT_V_WAVES) void k_traverse(SceneView sc, PathState ps, RayQueue queue, ShadowQueue sq,
-                                                                         uint32_t cap, Counters* __restrict__ cnt, int it_closest, int it_shadow)
+                                                                         uint32_t cap, Counters* __restrict__ cnt, int it_closest, int it_shadow, uint32_t sel)
 {
     __shared__ int s_stack[(FOVPT_STACK + 4) * FOVPT_TQUADS];  // + the end marker and three rows of slack above the top
     if (MODE == 0) it_shadow = -1;
     if (MODE == 1) it_closest = -1;
     ShardMap ms, mq;
-    if (MODE != 0) ms.load(cnt, FOVPT_CNT_SQ(it_shadow >= 0 ? it_shadow : 0));
-    if (MODE != 1) mq.load(cnt, FOVPT_CNT_Q(it_closest >= 0 ? it_closest : 0));
+    if (MODE != 0) ms.load(cnt, FOVPT_CNT_SQ(it_shadow >= 0 ? it_shadow : 0), sel, cap);
+    if (MODE != 1) mq.load(cnt, FOVPT_CNT_Q(it_closest >= 0 ? it_closest : 0), sel, cap);
     const uint32_t n_sh = (MODE != 0 && it_shadow >= 0) ? ms.total() : 0u;
     const uint32_t n_cl = (MODE != 1 && it_closest >= 0) ? mq.total() : 0u;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1138,11 +1149,11 @@ __device__ inline float4 tex2d(const TexDev& T, float u, float v)
 template <bool EXTRA>
 __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const FrameDev fd, SceneView sc, PathState ps,
                                                        RayQueue queue_in, RayQueue queue_out,
-                                                       ShadowQueue sq, uint32_t cap, Counters* __restrict__ cnt, int depth_iter)
+                                                       ShadowQueue sq, uint32_t cap, Counters* __restrict__ cnt, int depth_iter, uint32_t sel)
 {
     __shared__ uint32_t s_scratch[10];
     ShardMap mq;
-    mq.load(cnt, FOVPT_CNT_Q(depth_iter));
+    mq.load(cnt, FOVPT_CNT_Q(depth_iter), sel, cap);
     const uint32_t n = mq.total();
     const uint32_t nround = (n + FOVPT_BLOCK - 1) / FOVPT_BLOCK * FOVPT_BLOCK;
     for (uint32_t i = blockIdx.x * FOVPT_BLOCK + threadIdx.x; i < nround; i += gridDim.x * FOVPT_BLOCK) {
@@ -1329,7 +1340,7 @@ __global__ __launch_bounds__(FOVPT_BLOCK, FOVPT_V_SHADEWAVES) void k_shade(const
         }
         // ---- wavefront-ballot compaction into the next queues
         uint32_t spos, qpos;
-        block_append2(cnt, FOVPT_CNT_SQ(depth_iter), want_shadow, FOVPT_CNT_Q(depth_iter + 1), want_next, cap, s_scratch, spos, qpos);
+        block_append2(cnt, FOVPT_CNT_SQ(depth_iter), want_shadow, FOVPT_CNT_Q(depth_iter + 1), want_next, cap, s_scratch, spos, qpos, sel);
         if (want_shadow) { sq.o[spos] = sh_o; sq.d[spos] = sh_d; sq.val_vis[spos] = sh_vis; sq.val_occ[spos] = sh_occ; }
         if (want_next) { queue_out.o[qpos] = f4(next_o, __uint_as_float(slot)); queue_out.d[qpos] = f4(next_d, next_pdf); }
     }
@@ -1806,12 +1817,13 @@ __global__ void k_math(int op, const float* a, const float* b, float* out, size_
 }  // namespace
 
 // ------------------------------------------------------------------------------------------
-void fovpt_launch_generate(hipStream_t st, const FrameDev& fd, PathState ps, RayQueue queue0, uint32_t cap, Counters* cnt, uint32_t total_slots, int grid)
+void fovpt_launch_generate(hipStream_t st, const FrameDev& fd, PathState ps, RayQueue queue0, uint32_t cap, Counters* cnt, uint32_t slot_begin,
+                           uint32_t slot_end, int grid, uint32_t sel)
 {
-    hipLaunchKernelGGL(k_generate, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, ps, queue0, cap, cnt, total_slots);
+    hipLaunchKernelGGL(k_generate, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, ps, queue0, cap, cnt, slot_begin, slot_end, sel);
 }
 void fovpt_launch_traverse(hipStream_t st, SceneView sc, PathState ps, RayQueue queue, ShadowQueue sq, uint32_t cap,
-                           Counters* cnt, int it_closest, int it_shadow, int grid, hipEvent_t done)
+                           Counters* cnt, int it_closest, int it_shadow, int grid, hipEvent_t done, uint32_t sel)
 {
     // `done` rides on the kernel's own completion signal (no separate marker packet in the queue)
     // (`grid` counts blocks of 256 threads, as for the other kernels; the traversal block may be larger)
@@ -1819,22 +1831,22 @@ void fovpt_launch_traverse(hipStream_t st, SceneView sc, PathState ps, RayQueue 
     if (it_shadow < 0) {
         // a closest-hit launch reads at most 8 * cap rays (the shards' capacities): no more workgroups than it can have rounds of
         // FOVPT_TQUADS rays (what matters for the small frames of a 1/N shard)
-        const unsigned long long rounds = (8ull * cap + FOVPT_TQUADS - 1) / FOVPT_TQUADS;
+        const unsigned long long rounds = ((sel ? 4ull : 8ull) * cap + FOVPT_TQUADS - 1) / FOVPT_TQUADS;
         if ((unsigned long long)blocks > rounds) blocks = (int)((rounds + FOVPT_SHARDS - 1) / FOVPT_SHARDS * FOVPT_SHARDS);
     }
     auto kernel = it_shadow < 0 ? k_traverse<0> : it_closest < 0 ? k_traverse<1> : k_traverse<2>;
-    if (done) hipExtLaunchKernelGGL(kernel, dim3(blocks), dim3(FOVPT_TBLOCK), 0, st, nullptr, done, 0, sc, ps, queue, sq, cap, cnt, it_closest, it_shadow);
-    else hipLaunchKernelGGL(kernel, dim3(blocks), dim3(FOVPT_TBLOCK), 0, st, sc, ps, queue, sq, cap, cnt, it_closest, it_shadow);
+    if (done) hipExtLaunchKernelGGL(kernel, dim3(blocks), dim3(FOVPT_TBLOCK), 0, st, nullptr, done, 0, sc, ps, queue, sq, cap, cnt, it_closest, it_shadow, sel);
+    else hipLaunchKernelGGL(kernel, dim3(blocks), dim3(FOVPT_TBLOCK), 0, st, sc, ps, queue, sq, cap, cnt, it_closest, it_shadow, sel);
 }
 void fovpt_launch_shade(hipStream_t st, const FrameDev& fd, SceneView sc, PathState ps, RayQueue queue_in, RayQueue queue_out,
-                        ShadowQueue sq, uint32_t cap, Counters* cnt, int depth, int grid, hipEvent_t done)
+                        ShadowQueue sq, uint32_t cap, Counters* cnt, int depth, int grid, hipEvent_t done, uint32_t sel)
 {
     if (fd.options) {
-        if (done) hipExtLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(FOVPT_BLOCK), 0, st, nullptr, done, 0, fd, sc, ps, queue_in, queue_out, sq, cap, cnt, depth);
-        else hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, sc, ps, queue_in, queue_out, sq, cap, cnt, depth);
+        if (done) hipExtLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(FOVPT_BLOCK), 0, st, nullptr, done, 0, fd, sc, ps, queue_in, queue_out, sq, cap, cnt, depth, sel);
+        else hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, sc, ps, queue_in, queue_out, sq, cap, cnt, depth, sel);
     } else {
-        if (done) hipExtLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(FOVPT_BLOCK), 0, st, nullptr, done, 0, fd, sc, ps, queue_in, queue_out, sq, cap, cnt, depth);
-        else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, sc, ps, queue_in, queue_out, sq, cap, cnt, depth);
+        if (done) hipExtLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(FOVPT_BLOCK), 0, st, nullptr, done, 0, fd, sc, ps, queue_in, queue_out, sq, cap, cnt, depth, sel);
+        else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, sc, ps, queue_in, queue_out, sq, cap, cnt, depth, sel);
     }
 }
 void fovpt_launch_resolve(hipStream_t st, const FrameDev& fd, PathState ps, Counters* cnt, hipEvent_t done)

@@ -170,6 +170,12 @@ typedef struct fovpt_config {
                                    2 = two (highest throughput: each chain fills the other's gaps; a frame then takes
                                    about twice as long from first to last kernel).  Results do not depend on it: resolves
                                    run in issue order, and fovpt_stream() is ordered behind every finished frame.        */
+    int32_t chains_per_frame;   /* 0 / 1 = a frame is one chain of dependent launches; 2 = every frame is rendered as TWO
+                                   independent chains over halves of its sample slots (each with four of the eight queue
+                                   shards, on its own stream pair) and resolved once: for a caller that synchronises after
+                                   every frame, as the reference's main loop does, this shortens the frame the way
+                                   frames_in_flight = 2 shortens the interval between frames of one that does not.  With 2,
+                                   frames are issued one at a time (frames_in_flight is ignored).  Results do not depend on it. */
 } fovpt_config;
 
 /* fovpt_config.options.  Both are NON-PARITY modes with respect to the reference (it has neither); the CPU oracle

@@ -174,18 +174,20 @@ def test_torch_external_stream_orders_after_the_frame():
 
 @pytest.mark.parametrize("accumulate", [0, 1])
 def test_frames_in_flight_do_not_change_the_frames(accumulate):
-    """fovpt_config.frames_in_flight: with two frames in flight the main chains of consecutive frames run beside each other
-    on two stream pairs; every frame must still come out as with one -- resolves in issue order (progressive accumulation
+    """fovpt_config.frames_in_flight / chains_per_frame: with two frames in flight the main chains of consecutive frames run
+    beside each other on two stream pairs, with two chains per frame the halves of ONE frame do; every frame must still come
+    out as with one -- resolves in issue order (progressive accumulation
     makes frame k depend on frame k-1), and work the caller queues on fovpt_stream() between two frames ordered between them
     (each frame is copied out and the ONE frame buffer cleared right behind it, six frames back to back, no host sync)."""
     import torch
     size = (320, 180)
     n = 6
     got = {}
-    for fif in (1, 2):
+    for fif in (1, 2, 0):
         cfg = cfg_foveated(24, 80, (1, 2, 4))
         cfg.accumulate = accumulate
-        cfg.frames_in_flight = fif
+        cfg.frames_in_flight = fif if fif > 0 else 1
+        cfg.chains_per_frame = 2 if fif == 0 else 1                                  # "0": one frame at a time, as two chains
         r = make_gpu(scenes.atrium(9000), scenes.sky_probe(), scenes.ATRIUM_CAMERA, size, cfg, gaze=(200, 70))
         frame = torch.zeros(size[0] * size[1], dtype=torch.int32, device="cuda")
         ext = torch.cuda.ExternalStream(r.stream)
@@ -203,9 +205,10 @@ def test_frames_in_flight_do_not_change_the_frames(accumulate):
         ext.synchronize()
         got[fif] = ([c.cpu() for c in copies], r.downloadAccum().copy())
         r.close()
-    for a, b in zip(got[1][0], got[2][0]):
-        assert torch.equal(a, b) and int((a != 0).sum()) > 0.9 * a.numel()
-    assert _eq(got[1][1], got[2][1])
+    for other in (2, 0):
+        for a, b in zip(got[1][0], got[other][0]):
+            assert torch.equal(a, b) and int((a != 0).sum()) > 0.9 * a.numel()
+        assert _eq(got[1][1], got[other][1])
     if not accumulate:
         assert not torch.equal(got[1][0][0], got[1][0][-1])                       # (the camera did move)
 
@@ -622,6 +625,7 @@ def test_random_lifecycle(oracle, seed):
                 cfg = cfg_foveated(r_i, r_i + int(rng.integers(1, 40)), tuple(int(x) for x in rng.integers(1, 5, 3)), max_depth=int(rng.integers(1, 5)))
             cfg.accumulate = int(rng.random() < 0.4)
             cfg.frames_in_flight = int(seed * 7 + step) % 3              # 0 (= the default, 2), 1 or 2: never changes a frame
+            cfg.chains_per_frame = int(seed * 5 + step) % 3              # 0 / 1: one chain per frame, 2: two (frames >= 16384 slots)
             r.config = cfg
         elif op == 4:                                                 # the application resets the subframe counter
             sub = int(rng.integers(0, 3))
