@@ -87,6 +87,7 @@ struct fovpt_ctx {
     hipStream_t lane_main[FOVPT_MAX_LANES] = {}, lane_shadow[FOVPT_MAX_LANES] = {};   // [0] = stream / shadow_stream
     int lanes = FOVPT_LANES_DEFAULT;
     int chains_default = 1;                // what fovpt_config.chains_per_frame = 0 means (FOVPT_CHAINS)
+    int partition = 1;                     // direction classes in k_shade's appends: 0 never, 1 foveated frames, 2 always (FOVPT_PARTITION)
     std::string err;
     fovpt_config cfg;
     // scene
@@ -377,6 +378,7 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     fd.max_depth = c->cfg.max_depth;
     fd.accumulate = c->cfg.accumulate;
     fd.options = c->cfg.options;
+    fd.partition = (c->partition == 2 || (c->partition == 1 && !c->cfg.uniform)) ? 1 : 0;
     fd.rank = c->cfg.rank; fd.world = c->cfg.world < 1 ? 1 : c->cfg.world;
     fd.tile_w = c->cfg.tile_w > 0 ? c->cfg.tile_w : 8; fd.tile_h = c->cfg.tile_h > 0 ? c->cfg.tile_h : 4;
 
@@ -596,6 +598,7 @@ int fovpt_create(fovpt_ctx** out, int device)
     e = hipStreamCreateWithPriority(&c->stream, hipStreamDefault, prio_hi);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->shadow_stream, hipStreamDefault, prio_lo);
     if (const char* l = getenv("FOVPT_LANES")) { const int v = atoi(l); if (v >= 1 && v <= FOVPT_MAX_LANES) c->lanes = v; }
+    if (const char* l = getenv("FOVPT_PARTITION")) { const int v = atoi(l); if (v >= 0 && v <= 2) c->partition = v; }
     if (const char* l = getenv("FOVPT_CHAINS")) { const int v = atoi(l); if (v == 1 || v == 2) c->chains_default = v; }
     c->nsets = c->lanes < 2 ? 2u : (unsigned)c->lanes;
     c->lane_main[0] = c->stream; c->lane_shadow[0] = c->shadow_stream;

@@ -129,6 +129,7 @@ struct FrameDev {
     int32_t chunked;              // 1: this job is one of several over the same frame
     int32_t zero_holes;           // 1: clear the pixels no launch index of this job writes (a whole frame on a rank other than 0)
     int32_t options;              // fovpt_config.options (FOVPT_OPT_*): opt-in extensions, 0 = the reference's behaviour
+    int32_t partition;            // 1: k_shade appends a block's next rays in two direction classes (foveated frames), see block_append2d
 };
 
 // Per-sample-slot path state (SoA, 16-B vectors so every access is one dwordx4).
