@@ -469,10 +469,14 @@ def main():
     # its constant term (profiles/r03c_step_probes.txt).  TA cycles per wave-level load instruction and the
     # load instructions per launch are measured in this run when the counter passes ran.
     l1_path = None
+    dev_props = torch.cuda.get_device_properties(local_rank)
+    cus = int(getattr(dev_props, "multi_processor_count", CUS) or CUS)                       # 256 on MI355X: from the device, not assumed
+    clock_hz = float(getattr(dev_props, "clock_rate", 0) or 0) * 1e3 or CLOCK_HZ            # the device's engine clock (kHz -> Hz), else 2.4 GHz
+    l1_frac = None
     if counters and dom in counters and counters[dom].get("TA_FLAT_READ_WAVEFRONTS_sum"):
         c = counters[dom]
         per_inst = c["TA_TA_BUSY_sum"] / c["TA_FLAT_READ_WAVEFRONTS_sum"]
-        ta_ms = c["TA_TA_BUSY_sum"] / CUS / CLOCK_HZ * 1e3
+        ta_ms = c["TA_TA_BUSY_sum"] / cus / clock_hz * 1e3
         frames_seen = max(1.0, counters.get("k_resolve", {}).get("launches_seen", 3))
         tot_busy = sum(counters[k].get("TA_TA_BUSY_sum", 0.0) * counters[k].get("launches_seen", 0) for k in counters
                        if k in ("k_generate", "k_traverse", "k_shade", "k_resolve"))
@@ -481,13 +485,16 @@ def main():
             "ta_cycles_per_load_instruction": round(per_inst, 2),
             "ta_time_ms_per_launch": round(ta_ms, 5),
             "ta_share_of_serialised_launch": round(ta_ms / max(1e-9, c.get("dur_us", 0.0) / 1e3), 4) if c.get("dur_us") else None,
-            "ta_time_ms_per_frame_all_kernels": round(tot_busy / frames_seen / CUS / CLOCK_HZ * 1e3, 4),
-            "ta_share_of_the_frame_interval": round(tot_busy / frames_seen / CUS / CLOCK_HZ * 1e3 / ms_per_step, 4),
-            "note": "TA_TA_BUSY / 256 CUs at 2.4 GHz (a lower bound on the time: the shader clock runs at ~2.2 GHz under this load); a 128-byte "
+            "ta_time_ms_per_frame_all_kernels": round(tot_busy / frames_seen / cus / clock_hz * 1e3, 4),
+            "ta_share_of_the_frame_interval": round(tot_busy / frames_seen / cus / clock_hz * 1e3 / ms_per_step, 4),
+            "cus": cus, "clock_ghz": round(clock_hz / 1e9, 3),
+            "note": "TA_TA_BUSY / (the device's CU count) at the device's engine clock (a lower bound on the time: under this load the shader clock "
+                    "runs ~8 % below it); a 128-byte "
                     "node is two 16-byte loads per lane = 2 x ~17 cycles of the CU's 64-byte-per-clock address path per wave step.  "
                     "`ta_share_of_the_frame_interval` is the roof this design runs against: the address paths' time for ALL of a frame's "
                     "loads over the frame interval of the timed region",
         }
+        l1_frac = l1_path["ta_share_of_the_frame_interval"]
     if traffic is None:
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         try:
@@ -524,8 +531,16 @@ def main():
         }
     except Exception as e:                                      # the line is still valid without the model
         latency_model = {"unavailable": "%s: %s" % (type(e).__name__, e)}
+    lanes_env = os.environ.get("FOVPT_LANES")
+    lanes_avail = int(lanes_env) if lanes_env and lanes_env.isdigit() and 1 <= int(lanes_env) <= 4 else 2
+    fif_effective = min(timed_fif if timed_fif > 0 else lanes_avail, lanes_avail)
     roofline = {
-        "bound": "latency",
+        # flat keys first (the driver's parser keeps these): what binds the kernel, how close it is to THAT roof, and the two
+        # figures that say why the contract's roofs do not bind
+        "bound": "l1_address_path",
+        "l1_frac": l1_frac,                                       # TA busy time of all of a frame's loads / frame interval (measured in this run, else null)
+        "lane_use": (valu or {}).get("lane_use"),                 # k_traverse: active lanes per issued vector instruction
+        "hbm_frac_measured": round(traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if (traffic and avg_ms > 0) else None,
         "bound_note": "neither of the contract's roofs binds k_traverse: HBM traffic is a sixth of the algorithmic bytes (the scene stays in "
                       "L2 / Infinity Cache).  A node step sits at the knee of the CU's own address / data path (`l1_path`: ~17 texture-addresser "
                       "cycles per wave-level load, two per node step; a third costs +19 %, one fewer returns nothing) and is paced by its "
@@ -533,21 +548,22 @@ def main():
                       "0.32 + 1.53 / (waves per SIMD) ms per frame -- with the vector ALUs about half busy (`valu`: half-empty waves, 16 "
                       "rays in lockstep).  DESIGN.md section 4 has the occupancy sweep and the three probes; `achieved`/`peak`/`frac` are the "
                       "contract's algorithmic-bytes figure against the 8 TB/s HBM roof",
-        "kernel": dom, "achieved": round(achieved_one, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved_one / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
-        "avg_launch_ms": round(avg_ms_one, 5), "avg_launch_ms_serialised": round(avg_ms_serialised, 5),
+        # the contract's figure, for the configuration `value` is timed in: algorithmic bytes per launch / the launch's
+        # HIP-event duration as the timed region runs (frames_in_flight as in `config`)
+        "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+        "avg_launch_ms": round(avg_ms, 5), "avg_launch_ms_serialised": round(avg_ms_serialised, 5),
         "frac_serialised": round(bytes_per_launch / (avg_ms_serialised * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if avg_ms_serialised > 0 else None,
-        "avg_launch_ms_two_frames_in_flight": round(avg_ms, 5),
-        "frac_two_frames_in_flight": round(achieved / HBM_PEAK_GBS, 5),
+        "avg_launch_ms_one_frame_in_flight": round(avg_ms_one, 5),
+        "frac_one_frame_in_flight": round(achieved_one / HBM_PEAK_GBS, 5),
         "launches_in_flight": round(in_flight, 3),
         "frac_aggregate": round(bytes_per_launch * launches_per_frame / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-        "frac_note": "`achieved` / `frac` divide one launch's algorithmic bytes by its HIP-event duration with ONE frame in flight (the "
-                     "launch shares the chip with the other stream's launches of its own frame: the figure of rounds 1-2, and a "
-                     "stable one).  The timed region keeps TWO frames in flight: then the traversal launches of two frames share the "
-                     "chip (`launches_in_flight` at any time), each lasts longer although more gets done per second (`value`), and "
-                     "how much longer depends on how the two frames' chains happen to interleave -- `frac_two_frames_in_flight` came "
-                     "out as 0.36-0.38 or 0.46-0.47 in runs with the same frame interval.  `frac_serialised` is the kernel alone on "
-                     "the chip, `frac_aggregate` all traversal bytes of a frame over the frame interval of the timed region",
+        "frac_note": "`achieved` / `frac` divide one launch's algorithmic bytes by its HIP-event duration AS THE TIMED REGION RUNS (with two "
+                     "frames in flight the traversal launches of two frames share the chip -- `launches_in_flight` at any time -- so each "
+                     "lasts longer although more gets done per second; how much longer depends on how the two chains interleave, and the "
+                     "figure has come out as 0.36-0.38 or 0.46-0.47 at the same frame interval).  `frac_one_frame_in_flight` is the same with "
+                     "one frame in flight (rounds 1-3's `frac`, stable), `frac_serialised` the kernel alone on the chip, `frac_aggregate` all "
+                     "traversal bytes of a frame over the frame interval of the timed region",
         "launches_per_frame": launches_per_frame,
         "rays_per_launch": n_rays / max(1, n_launch), "algorithmic_bytes_per_ray": round(b_ray, 1),
         "per_frame_ms": per_frame_ms["overlapped"], "per_frame_ms_serialised": per_frame_ms["serialised"],
@@ -561,6 +577,9 @@ def main():
         "metric": "Mray/s", "value": round(mrays, 2), "unit": "Mray/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
         "frame_latency_ms": round(frame_latency_ms, 4),
+        # SURVEY 8(d)'s own definition of the metric -- wall time of render() INCLUDING its final synchronisation, one frame at a
+        # time as the reference's main loop runs -- beside the pipelined `value`
+        "value_sync_per_frame": round(rays_total / args.steps / (frame_latency_ms * 1e-3) / 1e6, 2) if world == 1 else None,
         "two_chains_per_frame": two_chains,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
@@ -573,7 +592,7 @@ def main():
             "rays_per_frame": rays_total / args.steps,
             "subframe": "advancing" if args.advance_subframe else "reset to 0 every frame (as the shipped app)",
             "parallelism": "tile-shard x%d + %s gather" % (world, args.gather) if world > 1 else "single GPU",
-            "frames_in_flight": args.frames_in_flight or 2,
+            "frames_in_flight": fif_effective,
             "gather": gather_mode,
         },
         "roofline": roofline,

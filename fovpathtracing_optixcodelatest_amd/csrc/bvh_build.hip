@@ -297,6 +297,186 @@ __global__ void k_lbvh_generic(int n, const int* __restrict__ rfirst, const int*
 
 struct Work4 { int node; uint32_t out; uint32_t depth; };
 
+__device__ inline float box_area(const Box& b);
+
+// ------------------------------------------------------------------------------------------
+// Reinsertion (after Meister & Bittner 2018, "Parallel reinsertion for bounding volume hierarchy optimization") on the binary
+// tree PLOC leaves behind, before the 2 -> 4 collapse.  PLOC merges what lies close on the Morton curve; what it cannot see is
+// that a subtree would sit better somewhere else entirely -- a large foliage card among the small triangles of a facade.  Every
+// node x (leaf or internal, not the root or one of its children) looks for the position that lowers the tree's SAH cost (the sum
+// of the internal nodes' surface areas) most: x and its parent p are taken out (p's other child s takes p's place, the
+// ancestors above shrink), and p is put back as the parent of (x, y) for some node y, whose ancestors grow.  The search climbs
+// from p to the root; at every level it descends into the subtree that hangs off the path there, branch and bound:
+//     gain(y) = G_k - inc(y) - A(x u y),   G_k = A(p) + what the path's nodes below level k shrink by,
+//     inc(y)  = what y's ancestors inside that subtree grow by,          and below y no gain exceeds G_k - inc'(y) - A(x).
+// Moves conflict when they touch the same nodes; every move stamps (gain, x) with atomicMax on the six nodes whose links it
+// rewrites (x, p, s, p's parent, y, y's parent) and on the ancestors of y below the search level (so that two subtrees cannot
+// be moved into each other), and only a move that still owns all its stamps is carried out.  Then the boxes are refitted and
+// the next round starts.  The tree's shape changes, the set of triangles below the root does not, and no shape changes a
+// result (include/fovpt.h) -- only the node steps per ray.
+// ------------------------------------------------------------------------------------------
+struct TreeView {
+    int n;                                  // leaves; internal nodes 0 .. n-2 (root = n-2 for PLOC), leaf l is coded ~l
+    int *left, *right, *parent_int, *parent_leaf;
+    Box* ibox;
+    const Box* boxes;
+    const uint32_t* vals;
+    __device__ inline Box box(int c) const { return c < 0 ? boxes[vals[~c]] : ibox[c]; }
+    __device__ inline int parent(int c) const { return c < 0 ? parent_leaf[~c] : parent_int[c]; }
+    __device__ inline uint32_t slot(int c) const { return c < 0 ? (uint32_t)(n - 1) + (uint32_t)~c : (uint32_t)c; }      // index into per-node arrays
+};
+__device__ inline float merged_area(const Box& a, const Box& b) { return union_area(a, b); }
+
+struct Move { int out; int pivot; float gain; };
+
+#define FOVPT_REINSERT_STACK 96
+#ifndef FOVPT_REINSERT_DEFAULT
+#define FOVPT_REINSERT_DEFAULT 0
+#endif
+__global__ void k_reinsert_find(TreeView T, int root, Move* __restrict__ moves, uint32_t phase, uint32_t phases)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= (uint32_t)(2 * T.n - 1)) return;
+    Move mv; mv.out = 0; mv.pivot = -1; mv.gain = 0.f;
+    const int c = x < (uint32_t)(T.n - 1) ? (int)x : ~(int)(x - (uint32_t)(T.n - 1));
+    const int p = T.parent(c);
+    if (c == root || p < 0 || p == root || (phases > 1u && (x % phases) != phase)) { moves[x] = mv; return; }
+    const Box bin = T.box(c);
+    const float a_in = box_area(bin);
+    float G = box_area(T.ibox[p]);
+    Box shrunk = bin;                                   // (overwritten at level 0)
+    int path_child = c, pivot = p, level = 0;
+    int st_node[FOVPT_REINSERT_STACK];
+    float st_inc[FOVPT_REINSERT_STACK];
+    while (pivot >= 0) {
+        const int l = T.left[pivot], r = T.right[pivot];
+        const int sib = l == path_child ? r : l;
+        const Box bs = T.box(sib);
+        {
+            // the subtree that hangs off the path at this level, root first
+            int sp = 0;
+            const float m = merged_area(bin, bs);
+            if (level > 0) { const float g = G - m; if (g > mv.gain) { mv.gain = g; mv.out = sib; mv.pivot = pivot; } }      // (level 0: beside its own sibling = where it is)
+            if (sib >= 0) { const float inc = m - box_area(bs); if (G - inc - a_in > mv.gain) { st_node[0] = sib; st_inc[0] = inc; sp = 1; } }
+            while (sp > 0) {
+                const int y = st_node[--sp];
+                const float inc = st_inc[sp];
+                if (!(G - inc - a_in > mv.gain)) continue;               // (the bound may have tightened since the push)
+                const int ch[2] = {T.left[y], T.right[y]};
+                float mc[2], ic[2];
+                for (int k = 0; k < 2; k++) {
+                    const Box bc = T.box(ch[k]);
+                    mc[k] = merged_area(bin, bc);
+                    ic[k] = inc + mc[k] - box_area(bc);
+                    const float g = G - inc - mc[k];
+                    if (g > mv.gain) { mv.gain = g; mv.out = ch[k]; mv.pivot = pivot; }
+                }
+                // the more promising child is popped first
+                const int first = mc[0] <= mc[1] ? 0 : 1;
+                for (int q = 1; q >= 0; q--) {
+                    const int k = q ? 1 - first : first;
+                    if (ch[k] >= 0 && G - ic[k] - a_in > mv.gain && sp < FOVPT_REINSERT_STACK) { st_node[sp] = ch[k]; st_inc[sp] = ic[k]; sp++; }
+                }
+            }
+        }
+        // one level up: `pivot` becomes a node of the path, with the box of what stays below it
+        if (level == 0) shrunk = bs;
+        else {
+            for (int k = 0; k < 3; k++) { shrunk.lo[k] = fminf(shrunk.lo[k], bs.lo[k]); shrunk.hi[k] = fmaxf(shrunk.hi[k], bs.hi[k]); }
+            G += box_area(T.ibox[pivot]) - box_area(shrunk);
+        }
+        path_child = pivot; pivot = T.parent_int[pivot]; level++;
+    }
+    // (a gain that is noise against the areas involved is no gain)
+    if (!(mv.gain > 1e-6f * G)) { mv.pivot = -1; mv.gain = 0.f; }
+    moves[x] = mv;
+}
+
+// the nodes a move touches: x, p, s, q = parent(p), y, parent(y) and y's further ancestors below the search level
+template <typename F> __device__ inline void reinsert_touch(const TreeView& T, int c, const Move& mv, F&& f)
+{
+    const int p = T.parent(c), q = T.parent_int[p];
+    const int s = T.left[p] == c ? T.right[p] : T.left[p];
+    f(T.slot(c)); f(T.slot(p)); f(T.slot(s)); f(T.slot(q)); f(T.slot(mv.out));
+    int a = T.parent(mv.out);
+    f(T.slot(a));                                     // y's parent gets a new child: owned even when it is the search level's node itself
+    while (a != mv.pivot) {
+        a = T.parent_int[a];
+        if (a < 0 || a == mv.pivot) break;
+        f(T.slot(a));
+    }
+}
+__global__ void k_reinsert_lock(TreeView T, const Move* __restrict__ moves, unsigned long long* __restrict__ lock)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= (uint32_t)(2 * T.n - 1)) return;
+    const Move mv = moves[x];
+    if (mv.pivot < 0) return;
+    const int c = x < (uint32_t)(T.n - 1) ? (int)x : ~(int)(x - (uint32_t)(T.n - 1));
+    const unsigned long long key = ((unsigned long long)__float_as_uint(mv.gain) << 32) | (unsigned long long)x;
+    reinsert_touch(T, c, mv, [&](uint32_t i) { atomicMax(&lock[i], key); });
+}
+__global__ void k_reinsert_check(TreeView T, Move* __restrict__ moves, const unsigned long long* __restrict__ lock, uint32_t* __restrict__ applied)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= (uint32_t)(2 * T.n - 1)) return;
+    Move mv = moves[x];
+    if (mv.pivot < 0) return;
+    const int c = x < (uint32_t)(T.n - 1) ? (int)x : ~(int)(x - (uint32_t)(T.n - 1));
+    const unsigned long long key = ((unsigned long long)__float_as_uint(mv.gain) << 32) | (unsigned long long)x;
+    bool mine = true;
+    reinsert_touch(T, c, mv, [&](uint32_t i) { if (lock[i] != key) mine = false; });
+    if (!mine) { mv.pivot = -1; moves[x] = mv; }
+    else atomicAdd(applied, 1u);
+}
+__device__ inline void set_parent(const TreeView& T, int c, int p) { if (c < 0) T.parent_leaf[~c] = p; else T.parent_int[c] = p; }
+__global__ void k_reinsert_apply(TreeView T, const Move* __restrict__ moves)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= (uint32_t)(2 * T.n - 1)) return;
+    const Move mv = moves[x];
+    if (mv.pivot < 0) return;
+    // every link written here belongs to a node this move owns (k_reinsert_check), and no other surviving move reads it
+    const int c = x < (uint32_t)(T.n - 1) ? (int)x : ~(int)(x - (uint32_t)(T.n - 1));
+    const int p = T.parent(c), q = T.parent_int[p];
+    const int s = T.left[p] == c ? T.right[p] : T.left[p];
+    // p leaves: s takes its place under q
+    if (T.left[q] == p) T.left[q] = s; else T.right[q] = s;
+    set_parent(T, s, q);
+    // p returns as the parent of (x, y) where y was
+    const int y = mv.out;
+    const int py = T.parent(y);                       // (read after s moved: y may be s's child, never s itself)
+    if (T.left[py] == y) T.left[py] = p; else T.right[py] = p;
+    T.parent_int[p] = py;
+    if (T.left[p] == c) T.right[p] = y; else T.left[p] = y;
+    set_parent(T, y, p);
+}
+// boxes, subtree sizes and child sides of the whole tree, bottom-up (the second thread to arrive at a node does it, as k_refit)
+__global__ void k_tree_refit(TreeView T, uint32_t* __restrict__ size_int, unsigned char* __restrict__ side_int, unsigned char* __restrict__ side_leaf,
+                             uint32_t* __restrict__ arrive, float* __restrict__ cost)
+{
+    const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
+    if (leaf >= T.n) return;
+    int node = T.parent_leaf[leaf];
+    float local = 0.f;
+    while (node >= 0) {
+        __threadfence();
+        if (atomicAdd(&arrive[node], 1u) == 0u) break;
+        __threadfence();
+        const int lc = T.left[node], rc = T.right[node];
+        const Box a = T.box(lc), b = T.box(rc);
+        Box u;
+        for (int k = 0; k < 3; k++) { u.lo[k] = fminf(a.lo[k], b.lo[k]); u.hi[k] = fmaxf(a.hi[k], b.hi[k]); }
+        T.ibox[node] = u;
+        size_int[node] = (lc < 0 ? 1u : size_int[lc]) + (rc < 0 ? 1u : size_int[rc]);
+        if (lc < 0) side_leaf[~lc] = 0; else side_int[lc] = 0;
+        if (rc < 0) side_leaf[~rc] = 1; else side_int[rc] = 1;
+        local += box_area(u);
+        node = T.parent_int[node];
+    }
+    if (cost && local != 0.f) atomicAdd(cost, local);
+}
+
 __device__ inline float box_area(const Box& b)
 {
     const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
@@ -671,7 +851,7 @@ __global__ void k_split_emit(const float* __restrict__ flat, uint32_t n, const u
 }  // namespace
 
 hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* mesh_of_prim, uint32_t n_prims, int use_ploc, float split_budget,
-                            BvhBuildResult* out, char* err, size_t errlen)
+                            int reinsert, BvhBuildResult* out, char* err, size_t errlen)
 {
     uint32_t n = n_prims;                      // build primitives: triangles, or references of triangles when splits are on
     uint32_t *ref_prim = nullptr, *split_cnt = nullptr, *split_first = nullptr;
@@ -698,6 +878,14 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
     const char* order_env = getenv("FOVPT_BVH_ORDER");                            // 0: keep the collapse's child order (A/B)
     const bool order_children = !order_env || atoi(order_env) != 0;
     float2* order_pc = nullptr;
+    // reinsertion rounds on the PLOC tree (k_reinsert_find): FOVPT_REINSERT=<rounds>, 0 = off
+    const char* re_env = getenv("FOVPT_REINSERT");
+    const int reinsert_rounds = reinsert >= 0 ? reinsert : re_env ? atoi(re_env) : FOVPT_REINSERT_DEFAULT;
+    const bool verbose = getenv("FOVPT_BVH_VERBOSE") != nullptr;
+    bool tree_changed = false;
+    Move* re_moves = nullptr;
+    unsigned long long* re_lock = nullptr;
+    uint32_t *re_arrive = nullptr, *re_scalars = nullptr;
     uint32_t* dp_arrive = nullptr;
     uint32_t* counters = nullptr;
     BvhNode4* nodes = nullptr;
@@ -822,6 +1010,44 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
                 m = m2;
                 if (++rounds > 4096) { snprintf(err, errlen, "PLOC did not converge"); goto fail; }
             }
+            if (reinsert_rounds > 0 && n > 16) {
+                // ---- reinsertion rounds on the PLOC tree (see k_reinsert_find)
+                TreeView T;
+                T.n = (int)n; T.left = left; T.right = right; T.parent_int = parent_int; T.parent_leaf = parent_leaf;
+                T.ibox = ibox; T.boxes = boxes; T.vals = vals_s;
+                const uint32_t nall = 2 * n - 1, gall2 = (nall + B - 1) / B;
+                HC(hipMalloc(&re_moves, sizeof(Move) * (size_t)nall));
+                HC(hipMalloc(&re_lock, 8ull * nall));
+                HC(hipMalloc(&re_arrive, 4ull * ni));
+                HC(hipMalloc(&re_scalars, 8));
+                float cost0 = 0.f;
+                if (verbose) {
+                    HC(hipMemsetAsync(re_arrive, 0, 4ull * ni, st)); HC(hipMemsetAsync(re_scalars, 0, 8, st));
+                    hipLaunchKernelGGL(k_tree_refit, dim3(gn), dim3(B), 0, st, T, size_int, side_int, side_leaf, re_arrive, (float*)(re_scalars + 1));
+                    HC(hipMemcpyAsync(&cost0, re_scalars + 1, 4, hipMemcpyDeviceToHost, st));
+                    HC(hipStreamSynchronize(st));
+                    fprintf(stderr, "[fovpt bvh] PLOC tree: sum of internal areas %.6g\n", (double)cost0);
+                }
+                for (int round = 0; round < reinsert_rounds; round++) {
+                    uint32_t applied = 0;
+                    float cost = 0.f;
+                    hipLaunchKernelGGL(k_reinsert_find, dim3(gall2), dim3(B), 0, st, T, (int)n - 2, re_moves, 0u, 1u);
+                    HC(hipMemsetAsync(re_lock, 0, 8ull * nall, st));
+                    hipLaunchKernelGGL(k_reinsert_lock, dim3(gall2), dim3(B), 0, st, T, re_moves, re_lock);
+                    HC(hipMemsetAsync(re_scalars, 0, 8, st));
+                    hipLaunchKernelGGL(k_reinsert_check, dim3(gall2), dim3(B), 0, st, T, re_moves, re_lock, re_scalars);
+                    hipLaunchKernelGGL(k_reinsert_apply, dim3(gall2), dim3(B), 0, st, T, re_moves);
+                    HC(hipMemsetAsync(re_arrive, 0, 4ull * ni, st));
+                    hipLaunchKernelGGL(k_tree_refit, dim3(gn), dim3(B), 0, st, T, size_int, side_int, side_leaf, re_arrive, (float*)(re_scalars + 1));
+                    HC(hipMemcpyAsync(&applied, re_scalars, 4, hipMemcpyDeviceToHost, st));
+                    HC(hipMemcpyAsync(&cost, re_scalars + 1, 4, hipMemcpyDeviceToHost, st));
+                    HC(hipStreamSynchronize(st));
+                    HC(hipGetLastError());
+                    tree_changed = tree_changed || applied > 0;
+                    if (verbose) fprintf(stderr, "[fovpt bvh] reinsertion round %d: %u moves, sum of internal areas %.6g\n", round, applied, (double)cost);
+                    if ((uint64_t)applied * 2000u < n) break;                      // (nothing much left to gain)
+                }
+            }
             const uint32_t gall = (2 * n - 1 + B - 1) / B;
             hipLaunchKernelGGL(k_dfs_offsets, dim3(gall), dim3(B), 0, st, (int)n, left, parent_int, parent_leaf, side_int, side_leaf, size_int,
                                leaf_pos, node_first, node_depth);
@@ -829,7 +1055,7 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
         }
         // ---- 2 -> 4 collapse: costs bottom-up, then one launch per level of the wide tree
         HC(hipMalloc(&dp, sizeof(DpCost) * ni));
-        if (use_ploc) {
+        if (use_ploc && !tree_changed) {
             uint32_t first = 0;
             for (uint32_t end : round_end) {
                 if (end > first)
@@ -899,6 +1125,7 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
         out->num_nodes = h_stats[1];
         out->num_refs = n;
         out->max_depth = h_stats[0];
+        out->reinserted = tree_changed ? 1u : 0u;
         out->node_bytes = node_bytes;
         out->tri_bytes = tri_bytes;
     }
@@ -911,6 +1138,7 @@ fail:
     (void)hipFree(c_node); (void)hipFree(t_node); (void)hipFree(nn); (void)hipFree(c_box); (void)hipFree(t_box); (void)hipFree(valid); (void)hipFree(pos);
     (void)hipFree(node_counter); (void)hipFree(size_int); (void)hipFree(leaf_pos); (void)hipFree(node_first); (void)hipFree(node_depth);
     (void)hipFree(dp); (void)hipFree(dp_arrive); (void)hipFree(order_pc);
+    (void)hipFree(re_moves); (void)hipFree(re_lock); (void)hipFree(re_arrive); (void)hipFree(re_scalars);
     (void)hipFree(side_int); (void)hipFree(side_leaf); (void)hipFree(scan_temp); (void)hipFree(work_a); (void)hipFree(work_b); (void)hipFree(counters);
     return rc;
 }

@@ -260,6 +260,18 @@ int ensure_state(fovpt_ctx* c, StateSet& S, size_t slots, size_t launches, hipSt
     return FOVPT_OK;
 }
 
+// What the traversal and shading kernels see of the scene.
+SceneView scene_view(const fovpt_ctx* c)
+{
+    SceneView sc;
+    sc.nodes = c->nodes; sc.tris = c->tris; sc.tri_tc = (const float2*)c->tri_tc.p;
+    sc.meshes = (const MeshDev*)c->meshes.p; sc.textures = (const TexDev*)c->textures.p;
+    sc.num_tris = c->num_tris; sc.any_catcher = c->any_catcher;
+    sc.tri_off = (uint32_t)((const char*)c->tris - (const char*)c->nodes);
+    return sc;
+}
+
+
 int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_in, int npass, int chunked, int whole_frame);
 
 // The engine: all passes of one frame as one wavefront job (or several, for very large launches).
@@ -417,11 +429,7 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
         sq[k].o = (float4*)S.sq_o[k].p; sq[k].d = (float4*)S.sq_d[k].p;
         sq[k].val_vis = (float4*)S.sq_vis[k].p; sq[k].val_occ = (float4*)S.sq_occ[k].p;
     }
-    SceneView sc;
-    sc.nodes = c->nodes; sc.tris = c->tris; sc.tri_tc = (const float2*)c->tri_tc.p;
-    sc.meshes = (const MeshDev*)c->meshes.p; sc.textures = (const TexDev*)c->textures.p;
-    sc.num_tris = c->num_tris; sc.any_catcher = c->any_catcher;
-    sc.tri_off = (uint32_t)((const char*)c->tris - (const char*)c->nodes);
+    const SceneView sc = scene_view(c);
     Counters* cnt = (Counters*)S.counters.p;
     // (the queue counters are zero: at allocation, and again by the resolve of the set's previous job)
 #if FOVPT_V_STEPSTAT
@@ -747,7 +755,13 @@ int fovpt_set_scene(fovpt_ctx* c, const fovpt_mesh_desc* meshes, int num_meshes,
     float split_budget = FOVPT_SPLIT_BUDGET_DEFAULT;    // references added by spatial splits, as a fraction of the triangles
     if (const char* sb = getenv("FOVPT_SPLIT")) split_budget = (float)atof(sb);
     if (!(split_budget >= 0.f) || split_budget > 2.f) split_budget = 0.f;
-    hipError_t be = fovpt_build_lbvh(c->stream, d_flat, d_mesh_of, (uint32_t)ntri, use_ploc, split_budget, &br, errbuf, sizeof(errbuf));
+    hipError_t be = fovpt_build_lbvh(c->stream, d_flat, d_mesh_of, (uint32_t)ntri, use_ploc, split_budget, -1, &br, errbuf, sizeof(errbuf));
+    if (be == hipSuccess && br.reinserted && 3 * br.max_depth + 1 > FOVPT_STACK) {
+        // reinsertion lowers the tree's cost, not its depth: a hierarchy it made too deep for the traversal stack is built again without it
+        (void)hipFree(br.nodes);
+        memset(&br, 0, sizeof(br));
+        be = fovpt_build_lbvh(c->stream, d_flat, d_mesh_of, (uint32_t)ntri, use_ploc, split_budget, 0, &br, errbuf, sizeof(errbuf));
+    }
     (void)hipEventRecord(e1, c->stream);
     (void)hipEventSynchronize(e1);
     float ms = 0.f;
@@ -911,7 +925,7 @@ int fovpt_set_config(fovpt_ctx* c, const fovpt_config* cfg)
     if (cfg->world < 1 || cfg->rank < 0 || cfg->rank >= cfg->world) return fail(c, FOVPT_E_INVALID, "bad rank/world %d/%d", cfg->rank, cfg->world);
     if (cfg->spp_periphery < 1 || cfg->spp_middle < 1 || cfg->spp_fovea < 1 || cfg->spp_uniform < 1) return fail(c, FOVPT_E_INVALID, "spp must be >= 1");
     if (cfg->r_inner < 0 || cfg->r_outer < cfg->r_inner) return fail(c, FOVPT_E_INVALID, "bad radii");
-    if (cfg->frames_in_flight < 0 || cfg->frames_in_flight > FOVPT_MAX_LANES) return fail(c, FOVPT_E_INVALID, "frames_in_flight must be 0 (default), 1 or 2");
+    if (cfg->frames_in_flight < 0 || cfg->frames_in_flight > FOVPT_MAX_LANES) return fail(c, FOVPT_E_INVALID, "frames_in_flight must be 0 (the default) or 1 .. %d (more than the context's stream pairs, FOVPT_LANES, means all of them)", FOVPT_MAX_LANES);
     if (cfg->chains_per_frame < 0 || cfg->chains_per_frame > 2) return fail(c, FOVPT_E_INVALID, "chains_per_frame must be 0, 1 or 2");
     if (cfg->options & ~(FOVPT_OPT_SKY_MISS | FOVPT_OPT_RUSSIAN_ROULETTE)) return fail(c, FOVPT_E_INVALID, "unknown option bits %d", cfg->options);
     c->cfg = *cfg;
@@ -1125,12 +1139,22 @@ int fovpt_gather_frame(fovpt_ctx* c, const fovpt_launch_params* lp, int root, co
     if (rc) return rc;
     Rccl& R = rccl();
     hipStream_t st = c->shadow_stream;
+    // A group that was opened is always closed: the first failing call is remembered, the remaining point-to-point calls are
+    // skipped, ncclGroupEnd still runs (an open group would leave this rank's later collectives queued for ever and its peers
+    // blocked in theirs), and only then does the call fail.
     NCCLCHK(c, R.GroupStart());
+    ncclResult_t first_err = ncclSuccess;
+    const char* first_what = "";
     if (rank == root)
-        for (int r = 0; r < world; r++)
-            if (counts[r]) NCCLCHK(c, R.Recv((uint32_t*)c->comm_gathered.p + (size_t)r * stride, counts[r], ncclUint32, r, c->comm, st));
-    if (counts[rank]) NCCLCHK(c, R.Send(c->comm_packed.p, counts[rank], ncclUint32, root, c->comm, st));
-    NCCLCHK(c, R.GroupEnd());
+        for (int r = 0; r < world && first_err == ncclSuccess; r++)
+            if (counts[r]) {
+                first_err = R.Recv((uint32_t*)c->comm_gathered.p + (size_t)r * stride, counts[r], ncclUint32, r, c->comm, st);
+                first_what = "ncclRecv";
+            }
+    if (counts[rank] && first_err == ncclSuccess) { first_err = R.Send(c->comm_packed.p, counts[rank], ncclUint32, root, c->comm, st); first_what = "ncclSend"; }
+    const ncclResult_t end_err = R.GroupEnd();
+    if (first_err != ncclSuccess) return fail(c, FOVPT_E_DEVICE, "%s: %s", first_what, R.GetErrorString(first_err));
+    if (end_err != ncclSuccess) return fail(c, FOVPT_E_DEVICE, "ncclGroupEnd: %s", R.GetErrorString(end_err));
     if (rank == root) {
         rc = fovpt_gather_unpack(c, (const uint32_t*)c->comm_gathered.p, stride, full_frame);
         if (rc) return rc;
@@ -1304,11 +1328,7 @@ int fovpt_debug_trace(fovpt_ctx* c, int n, const float* origins3, const float* d
 #endif
     RayQueue q; q.o = (float4*)S.q_o[0].p; q.d = (float4*)S.q_d[0].p;
     ShadowQueue sq; sq.o = (float4*)S.sq_o[0].p; sq.d = (float4*)S.sq_d[0].p; sq.val_vis = (float4*)S.sq_vis[0].p; sq.val_occ = (float4*)S.sq_occ[0].p;
-    SceneView sc;
-    sc.nodes = c->nodes; sc.tris = c->tris; sc.tri_tc = (const float2*)c->tri_tc.p;
-    sc.meshes = (const MeshDev*)c->meshes.p; sc.textures = (const TexDev*)c->textures.p;
-    sc.num_tris = c->num_tris; sc.any_catcher = c->any_catcher;
-    sc.tri_off = (uint32_t)((const char*)c->tris - (const char*)c->nodes);
+    const SceneView sc = scene_view(c);
     fovpt_launch_traverse(st, sc, ps, q, sq, cap, cnt, 0, -1, c->grid_trace);        // closest hit, as run_job launches it
     fovpt_launch_traverse(st, sc, ps, q, sq, cap, cnt, -1, 0, c->grid_shadow);       // occlusion, as run_job launches it
     HIPCHK(c, hipGetLastError());

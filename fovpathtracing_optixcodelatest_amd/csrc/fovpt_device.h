@@ -15,6 +15,9 @@
 #ifndef FOVPT_V_CYCLES
 #define FOVPT_V_CYCLES 0           // 1: diagnostic build with s_memtime stamps inside the traversal steps (tools/stepcycles.py)
 #endif
+#ifndef FOVPT_V_PRUNE_NODE
+#define FOVPT_V_PRUNE_NODE 0       // 1: the pruning closest-hit build checks EVERY pop against the limit, not only those of a leaf step (A/B)
+#endif
 #ifndef FOVPT_LEAF_MAX
 #define FOVPT_LEAF_MAX 4          // triangles per BVH leaf (<= 8: three bits in the leaf code)
 #endif
@@ -199,13 +202,15 @@ struct BvhBuildResult {
     uint32_t num_nodes;           // wide nodes emitted (breadth-first order, root = 0)
     uint32_t num_refs;            // triangle records behind the nodes: the triangles, or more when triangles were split into references
     uint32_t max_depth;
+    uint32_t reinserted;          // 1: reinsertion rounds changed the PLOC tree
     size_t node_bytes, tri_bytes;
 };
 
 // flat: 9 floats per triangle (v0,v1,v2), mesh_of_prim: mesh id per triangle.  All device pointers.
 // split_budget: references added by spatial splits as a fraction of the triangles (0 = none), see bvh_build.hip.
+// reinsert: rounds of reinsertion on the PLOC tree (0 = none, -1 = FOVPT_REINSERT or the build's default).
 hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* mesh_of_prim, uint32_t n, int use_ploc, float split_budget,
-                            BvhBuildResult* out, char* err, size_t errlen);
+                            int reinsert, BvhBuildResult* out, char* err, size_t errlen);
 
 // cap = shard capacity (in items) of the radiance queues and of the shadow queue.
 // sel: 0 = all eight queue shards (a whole job); 1 / 2 = the first / second four (one of the two chains of a frame)

@@ -1,7 +1,11 @@
 // model_loader.cpp -- host-side scene ingestion behind the C ABI (fovpt_model_*, include/fovpt.h): what a C++ caller
 // of the reference gets from loadOBJ (PT_sv5_/Model.cpp:138-217), addVertex (:49-82) and loadTexture (:84-136), i.e.
 // from the vendored tinyobjloader 2.0.0-rc (support/tinyobjloader, LoadObj with triangulate = true) and stb_image
-// (stbi_load(..., STBI_rgb_alpha)).  Written from the behaviour, not from their text; pinned to the reference's own
+// (stbi_load(..., STBI_rgb_alpha)).  OBJ / MTL, PNG, TGA, PPM, HDR and glTF are written from the formats' definitions and the
+// behaviour of those libraries, not from their text.  The JPEG decoder necessarily restates stb_image's NUMERIC choices (inverse
+// DCT, chroma filters, colour conversion: the standard leaves them to the decoder, see JpegDecoder) -- stb_image is public domain /
+// MIT (Sean Barrett et al.), its transform the Independent JPEG Group's; the entropy decoding is the standard's own procedure
+// (T.81 annex F, figure F.16).  Everything is pinned to the reference's own
 // output by tests/test_ref_pin_cpu.py (tests/golden/ref_loaders.npz and, where oracle/_ref exists, seeded random OBJ
 // files through both).  Plain host C++: no HIP, no GPU needed.
 //
@@ -16,7 +20,7 @@
 //     so a file named by two shapes is loaded twice
 //   * textures: PNG (all colour types and bit depths, tRNS, Adam7), Truevision TGA (the format of the reference's default
 //     scene: true colour, gray, colour-mapped, run-length forms) and binary PPM, as stbi_load returns them with four
-//     channels, then mirrored along y (:117-126).  Anything else (JPEG, ...) counts as "could not load": id -1 (:129-131).
+//     channels, then mirrored along y (:117-126), and JPEG (below).  Anything else counts as "could not load": id -1 (:129-131).
 #include <zlib.h>
 
 #include <cctype>
@@ -519,7 +523,18 @@ bool decode_tga(const std::vector<uint8_t>& d, Image& img)
 //     8 x 8 -> 8 multiply of the graphics literature ((t + (t >> 8)) >> 8, t = a b + 128).
 // Held against the reference's own stb_image through oracle/_ref (tests/golden/ref_jpeg.npz).
 struct JpegDecoder {
-    struct Huff { uint8_t size[257]; uint16_t code[256]; uint8_t value[256]; uint32_t maxcode[18]; int delta[17]; uint8_t fast[512]; bool ok = false; };
+    // One Huffman table in the standard's own terms (T.81 C.2 and F.2.2.3): the canonical code is given by how many codes
+    // there are of every length; a symbol is found by growing the code bit by bit until it is not beyond the largest code of
+    // its length (figure F.16: MINCODE / MAXCODE / VALPTR).  In front of that loop an 8-bit lookup answers the short codes.
+    struct Huff {
+        uint8_t value[256];           // HUFFVAL: the symbols in code order
+        int32_t maxcode[17];          // largest code of each length 1..16, -1 where there is none
+        uint16_t mincode[17];         // smallest code of each length
+        uint16_t valptr[17];          // index of that code's symbol in value[]
+        uint16_t look[256];           // the next 8 bits -> (code length << 8) | index into value[], 0: longer than 8 bits (or no code)
+        int count = 0;
+        bool ok = false;
+    };
     struct Comp {
         int id = 0, h = 1, v = 1, tq = 0, hd = 0, ha = 0, pred = 0;
         int x = 0, y = 0, w2 = 0, h2 = 0, bw = 0;               // valid samples, padded plane size, blocks per row
@@ -534,7 +549,7 @@ struct JpegDecoder {
     bool progressive = false, jfif = false;
     int adobe = -1, rgb_ids = 0, restart = 0;
     int scan_n = 0, order[4] = {0, 0, 0, 0}, ss = 0, se = 63, ah = 0, al = 0, eobrun = 0, todo = 0;
-    uint32_t bits = 0; int nbits = 0; int marker = 0xff; bool nomore = false;
+    int marker = 0xff; bool nomore = false;
 
     static const uint8_t* zigzag()
     {
@@ -547,74 +562,79 @@ struct JpegDecoder {
     int get16() { const int a = get8(); return (a << 8) | get8(); }
     void skip(int k) { pos = k < 0 ? n : std::min(n, pos + (size_t)k); }
 
-    bool build(Huff& h, const int* count)
+    bool build(Huff& h, const int* per_length)
     {
-        int k = 0;
-        for (int i = 0; i < 16; i++) for (int j = 0; j < count[i]; j++) { if (k >= 256) return false; h.size[k++] = (uint8_t)(i + 1); }
-        h.size[k] = 0;
-        unsigned code = 0;
-        int kk = 0;
-        for (int j = 1; j <= 16; j++) {
-            h.delta[j] = kk - (int)code;
-            if (h.size[kk] == j) {
-                while (h.size[kk] == j) h.code[kk++] = (uint16_t)(code++);
-                if (code - 1 >= (1u << j)) return false;
-            }
-            h.maxcode[j] = code << (16 - j);
-            code <<= 1;
+        // canonical assignment: the codes of one length are consecutive, the first of the next length is twice the successor of the
+        // last.  A table that runs out of codes of some length (more than 2^len of them so far) is refused, like the reference's
+        // reader refuses it ("bad code lengths").
+        h.ok = false;
+        unsigned next = 0;
+        int filled = 0;
+        memset(h.look, 0, sizeof(h.look));
+        for (int len = 1; len <= 16; len++) {
+            const int cnt = per_length[len - 1];
+            h.mincode[len] = (uint16_t)next; h.valptr[len] = (uint16_t)filled; h.maxcode[len] = cnt ? (int32_t)(next + (unsigned)cnt - 1u) : -1;
+            if (filled + cnt > 256) return false;
+            if (cnt && next + (unsigned)cnt > (1u << len)) return false;
+            if (len <= 8)
+                for (int c = 0; c < cnt; c++) {
+                    const unsigned first = (next + (unsigned)c) << (8 - len), span = 1u << (8 - len);
+                    for (unsigned e = 0; e < span; e++) h.look[first + e] = (uint16_t)((len << 8) | (filled + c));
+                }
+            next = (next + (unsigned)cnt) << 1;
+            filled += cnt;
         }
-        h.maxcode[17] = 0xffffffffu;
-        memset(h.fast, 255, sizeof(h.fast));
-        for (int i = 0; i < k; i++) {
-            const int sz = h.size[i];
-            if (sz <= 9) { const int c = h.code[i] << (9 - sz), m = 1 << (9 - sz); for (int j = 0; j < m; j++) h.fast[c + j] = (uint8_t)i; }
-        }
+        h.count = filled;
         h.ok = true;
         return true;
     }
-    // the entropy-coded segment: bytes until a marker; 0xff 0x00 is a data byte 0xff; after a marker (or the end of the file) zeros
-    void fill()
+    // The entropy-coded segment as a bit stream: `acc` holds the next `have` bits left-aligned.  0xff 0x00 is the data byte 0xff;
+    // 0xff followed by anything else is a marker -- it is remembered, and from there on (as past the end of the file) the stream
+    // reads as zeros, which is what the reference's reader feeds its decoder too.
+    uint64_t acc = 0; int have = 0;
+    void need(int k)
     {
-        do {
-            const unsigned b = nomore ? 0u : (unsigned)get8();
-            if (b == 0xff) {
-                int c = get8();
-                while (c == 0xff) c = get8();
-                if (c != 0) { marker = c; nomore = true; return; }
+        while (have < k) {
+            unsigned byte = 0;
+            if (!nomore) {
+                byte = (unsigned)get8();
+                if (byte == 0xff) {
+                    int c = get8();
+                    while (c == 0xff) c = get8();
+                    if (c != 0) { marker = c; nomore = true; byte = 0; }
+                }
             }
-            bits |= b << (24 - nbits);
-            nbits += 8;
-        } while (nbits <= 24);
+            acc |= (uint64_t)byte << (56 - have);
+            have += 8;
+        }
     }
+    unsigned peek(int k) { return (unsigned)(acc >> (64 - k)); }            // 1 <= k <= 32, after need(k)
+    void drop(int k) { acc <<= k; have -= k; }
     int decode(const Huff& h)
     {
-        if (nbits < 16) fill();
-        const int c = (int)(bits >> 23) & 511;
-        int k = h.fast[c];
-        if (k < 255) {
-            const int sz = h.size[k];
-            if (sz > nbits) return -1;
-            bits <<= sz; nbits -= sz;
-            return h.value[k];
+        need(32);
+        const unsigned e = h.look[peek(8)];
+        if (e) { drop((int)(e >> 8)); return h.value[e & 255u]; }
+        const unsigned w = peek(16);
+        for (int len = 9; len <= 16; len++) {
+            const int32_t code = (int32_t)(w >> (16 - len));
+            if (code <= h.maxcode[len]) {                                   // (maxcode -1: no code of this length)
+                if (code < (int32_t)h.mincode[len]) return -1;
+                drop(len);
+                return h.value[h.valptr[len] + (unsigned)(code - (int32_t)h.mincode[len])];
+            }
         }
-        const unsigned t = bits >> 16;
-        for (k = 10; ; k++) if (t < h.maxcode[k]) break;
-        if (k == 17) { nbits -= 16; return -1; }
-        if (k > nbits) return -1;
-        const int idx = (int)((bits >> (32 - k)) & ((1u << k) - 1u)) + h.delta[k];
-        if (idx < 0 || idx > 255) return -1;
-        nbits -= k; bits <<= k;
-        return h.value[idx];
+        return -1;                                                          // sixteen bits that are no code
     }
     int getbits(int k)
     {
         if (k <= 0 || k > 16) return 0;
-        if (nbits < k) fill();
-        const unsigned r = bits >> (32 - k);
-        bits <<= k; nbits -= k;
+        need(k);
+        const unsigned r = peek(k);
+        drop(k);
         return (int)r;
     }
-    int getbit() { if (nbits < 1) fill(); const unsigned r = bits >> 31; bits <<= 1; nbits--; return (int)r; }
+    int getbit() { return getbits(1); }
     int extend(int k)                                             // RECEIVE + EXTEND (T.81 F.2.2.1)
     {
         if (k <= 0 || k > 16) return 0;
@@ -623,51 +643,53 @@ struct JpegDecoder {
     }
     void reset()
     {
-        nbits = 0; bits = 0; nomore = false; marker = 0xff; eobrun = 0;
+        have = 0; acc = 0; nomore = false; marker = 0xff; eobrun = 0;
         for (int i = 0; i < 4; i++) comp[i].pred = 0;
         todo = restart ? restart : 0x7fffffff;
     }
 
+    // The inverse DCT.  JPEG does not fix it bit for bit, so matching the reference's pixels means matching ITS transform: the
+    // Loeffler-Ligtenberg-Moschytz factorisation in 12-bit fixed point as the Independent JPEG Group's jidctint.c has it and as
+    // stb_image (public domain / MIT, Sean Barrett et al.; the reference vendors it under support/stb) scales it -- columns first,
+    // kept with 2 extra bits, then rows down to the sample, + 128, clamped; a column whose AC terms are all zero is its DC term
+    // times 4.  The constants, shifts and roundings below are that transform's and are pinned by tests/golden/ref_jpeg.npz; this
+    // software is based in part on the work of the Independent JPEG Group.
     static int fix(float x) { return (int)(x * 4096 + 0.5); }
     static uint8_t clamp8(int x) { return (unsigned)x > 255u ? (x < 0 ? 0 : 255) : (uint8_t)x; }
-    // one 1-D pass of the transform on s[0..7] (stride st): even part into x0..x3, odd part into t0..t3
-    static void idct1(const int* s, int st, int& x0, int& x1, int& x2, int& x3, int& t0, int& t1, int& t2, int& t3)
+    // one 8-point pass over in[0], in[st], ...: sample k = even[k] + odd[k], sample 7 - k = even[k] - odd[k]  (k = 0..3)
+    static void lm8(const int* in, int st, int even[4], int odd[4])
     {
-        int p2 = s[2 * st], p3 = s[6 * st];
-        int p1 = (p2 + p3) * fix(0.5411961f);
-        t2 = p1 + p3 * fix(-1.847759065f);
-        t3 = p1 + p2 * fix(0.765366865f);
-        p2 = s[0]; p3 = s[4 * st];
-        t0 = (p2 + p3) * 4096; t1 = (p2 - p3) * 4096;
-        x0 = t0 + t3; x3 = t0 - t3; x1 = t1 + t2; x2 = t1 - t2;
-        t0 = s[7 * st]; t1 = s[5 * st]; t2 = s[3 * st]; t3 = s[1 * st];
-        p3 = t0 + t2; int p4 = t1 + t3; p1 = t0 + t3; p2 = t1 + t2;
-        const int p5 = (p3 + p4) * fix(1.175875602f);
-        t0 = t0 * fix(0.298631336f); t1 = t1 * fix(2.053119869f); t2 = t2 * fix(3.072711026f); t3 = t3 * fix(1.501321110f);
-        p1 = p5 + p1 * fix(-0.899976223f); p2 = p5 + p2 * fix(-2.562915447f); p3 = p3 * fix(-1.961570560f); p4 = p4 * fix(-0.390180644f);
-        t3 += p1 + p4; t2 += p2 + p3; t1 += p2 + p4; t0 += p1 + p3;
+        const int c2 = in[2 * st], c6 = in[6 * st];
+        const int z = (c2 + c6) * fix(0.5411961f);
+        const int lo = z + c6 * fix(-1.847759065f), hi = z + c2 * fix(0.765366865f);
+        const int sum = (in[0] + in[4 * st]) * 4096, dif = (in[0] - in[4 * st]) * 4096;
+        even[0] = sum + hi; even[3] = sum - hi; even[1] = dif + lo; even[2] = dif - lo;
+        const int c7 = in[7 * st], c5 = in[5 * st], c3 = in[3 * st], c1 = in[st];
+        const int a = c7 + c3, b = c5 + c1, c = c7 + c1, d = c5 + c3;
+        const int w = (a + b) * fix(1.175875602f);
+        const int pc = w + c * fix(-0.899976223f), pd = w + d * fix(-2.562915447f), pa = a * fix(-1.961570560f), pb = b * fix(-0.390180644f);
+        odd[3] = c7 * fix(0.298631336f) + (pc + pa);
+        odd[2] = c5 * fix(2.053119869f) + (pd + pb);
+        odd[1] = c3 * fix(3.072711026f) + (pd + pa);
+        odd[0] = c1 * fix(1.501321110f) + (pc + pb);
     }
     static void idct(uint8_t* out, int stride, const short* data)
     {
-        int in[64], val[64];
+        int in[64], mid[64], even[4], odd[4];
         for (int i = 0; i < 64; i++) in[i] = data[i];
-        for (int i = 0; i < 8; i++) {
-            const int* c = in + i; int* v = val + i;
-            if (!c[8] && !c[16] && !c[24] && !c[32] && !c[40] && !c[48] && !c[56]) { const int dc = c[0] * 4; for (int k = 0; k < 8; k++) v[8 * k] = dc; continue; }
-            int x0, x1, x2, x3, t0, t1, t2, t3;
-            idct1(c, 8, x0, x1, x2, x3, t0, t1, t2, t3);
-            x0 += 512; x1 += 512; x2 += 512; x3 += 512;
-            v[0] = (x0 + t3) >> 10; v[56] = (x0 - t3) >> 10; v[8] = (x1 + t2) >> 10; v[48] = (x1 - t2) >> 10;
-            v[16] = (x2 + t1) >> 10; v[40] = (x2 - t1) >> 10; v[24] = (x3 + t0) >> 10; v[32] = (x3 - t0) >> 10;
+        for (int x = 0; x < 8; x++) {                                     // columns -> mid, scaled by 4
+            const int* c = in + x;
+            bool flat = true;
+            for (int k = 1; k < 8; k++) if (c[8 * k]) flat = false;
+            if (flat) { for (int k = 0; k < 8; k++) mid[8 * k + x] = c[0] * 4; continue; }
+            lm8(c, 8, even, odd);
+            for (int k = 0; k < 4; k++) { mid[8 * k + x] = (even[k] + 512 + odd[k]) >> 10; mid[8 * (7 - k) + x] = (even[k] + 512 - odd[k]) >> 10; }
         }
-        for (int i = 0; i < 8; i++) {
-            int x0, x1, x2, x3, t0, t1, t2, t3;
-            idct1(val + 8 * i, 1, x0, x1, x2, x3, t0, t1, t2, t3);
+        for (int y = 0; y < 8; y++) {                                     // rows -> samples
+            lm8(mid + 8 * y, 1, even, odd);
+            uint8_t* o = out + (size_t)y * stride;
             const int bias = 65536 + (128 << 17);
-            x0 += bias; x1 += bias; x2 += bias; x3 += bias;
-            uint8_t* o = out + (size_t)i * stride;
-            o[0] = clamp8((x0 + t3) >> 17); o[7] = clamp8((x0 - t3) >> 17); o[1] = clamp8((x1 + t2) >> 17); o[6] = clamp8((x1 - t2) >> 17);
-            o[2] = clamp8((x2 + t1) >> 17); o[5] = clamp8((x2 - t1) >> 17); o[3] = clamp8((x3 + t0) >> 17); o[4] = clamp8((x3 - t0) >> 17);
+            for (int k = 0; k < 4; k++) { o[k] = clamp8((even[k] + bias + odd[k]) >> 17); o[7 - k] = clamp8((even[k] + bias - odd[k]) >> 17); }
         }
     }
 
@@ -763,7 +785,7 @@ struct JpegDecoder {
         };
         auto counted = [&]() -> int {                            // 0 go on, 1 the scan ends here
             if (--todo <= 0) {
-                if (nbits < 24) fill();
+                need(32);                                        // past the padding of the interval's last byte: the restart marker, if there is one
                 if (!(marker >= 0xd0 && marker <= 0xd7)) return 1;
                 reset();
             }
@@ -822,6 +844,7 @@ struct JpegDecoder {
                 Huff& h = tc == 0 ? hdc[th] : hac[th];
                 if (!build(h, sizes)) return false;
                 for (int i = 0; i < cnt; i++) h.value[i] = (uint8_t)get8();
+                for (int i = cnt; i < 256; i++) h.value[i] = 0;
                 L -= cnt;
             }
             return L == 0;
@@ -869,6 +892,9 @@ struct JpegDecoder {
         if ((uint64_t)width * (uint64_t)height > (1ull << 28)) return false;
         hmax = vmax = 1;
         for (int i = 0; i < ncomp; i++) { hmax = std::max(hmax, comp[i].h); vmax = std::max(vmax, comp[i].v); }
+        // (factors that do not divide the largest one have no integral upsampling ratio: image() would read past a plane's rows --
+        // a heap overflow that the vendored stb_image has too; newer ones refuse such files with "bad H" / "bad V", so does this)
+        for (int i = 0; i < ncomp; i++) if (hmax % comp[i].h != 0 || vmax % comp[i].v != 0) return false;
         mcux = (width + hmax * 8 - 1) / (hmax * 8); mcuy = (height + vmax * 8 - 1) / (vmax * 8);
         for (int i = 0; i < ncomp; i++) {
             Comp& C = comp[i];
@@ -1026,10 +1052,10 @@ bool ends_with_ci(const std::string& s, const char* suffix)
     return true;
 }
 
-bool load_texture_file(const std::string& path, Image& img)
+// an image file's bytes -> rgba8, mirrored along y; `name`: the file name (Truevision TGA has no signature: by extension, as the
+// python loader does) or empty for an image embedded in a glTF buffer / data URI
+bool decode_texture_bytes(const std::vector<uint8_t>& d, const std::string& path, Image& img)
 {
-    std::vector<uint8_t> d;
-    if (!read_file(path, d)) return false;
     bool ok = false;
     if (d.size() >= 8 && d[0] == 0x89 && d[1] == 'P') ok = decode_png(d, img);
     else if (d.size() >= 3 && d[0] == 0xff && d[1] == 0xd8 && d[2] == 0xff) ok = decode_jpeg(d, img);
@@ -1039,6 +1065,11 @@ bool load_texture_file(const std::string& path, Image& img)
     for (int y = 0; y < img.h / 2; y++)                                       // mirrored along y, Model.cpp:117-126
         for (int x = 0; x < img.w; x++) std::swap(img.px[(size_t)y * img.w + x], img.px[(size_t)(img.h - 1 - y) * img.w + x]);
     return true;
+}
+bool load_texture_file(const std::string& path, Image& img)
+{
+    std::vector<uint8_t> d;
+    return read_file(path, d) && decode_texture_bytes(d, path, img);
 }
 
 // ---- float4 texels as stbi_loadf(file, &w, &h, &n, 4) gives them (loadProbe, PT_sv5_/main.cpp:160-171) -------------
@@ -1159,7 +1190,13 @@ struct Json {
         return nullptr;
     }
     double number(const char* key, double dflt) const { const Json* v = get(key); return v && v->kind == Num ? v->num : dflt; }
-    long integer(const char* key, long dflt) const { const Json* v = get(key); return v && v->kind == Num ? (long)v->num : dflt; }
+    // (a number that is not finite or not within +-2^53 has no integer value: the default, which every caller treats as absent / invalid)
+    long integer(const char* key, long dflt) const
+    {
+        const Json* v = get(key);
+        if (!v || v->kind != Num || !(v->num >= -9007199254740992.0 && v->num <= 9007199254740992.0)) return dflt;
+        return (long)v->num;
+    }
 };
 struct JsonParser {
     const char* p; const char* end; int depth = 0;
@@ -1486,11 +1523,22 @@ static int model_load_gltf_impl(const char* file, fovpt_model** out)
         const Json& bv = jviews.arr[bi];
         const long buf = bv.integer("buffer", -1);
         if (buf < 0 || (size_t)buf >= buffers.size()) return false;
-        const size_t off = (size_t)bv.integer("byteOffset", 0) + (size_t)a.integer("byteOffset", 0), elem = esz * (size_t)nc;
-        size_t stride = (size_t)bv.integer("byteStride", 0);
-        if (!stride) stride = elem;
+        // offsets and stride come from the file: non-negative, bounded BEFORE any arithmetic, and the last element's end is checked
+        // by division (a product count * stride can wrap 64 bits)
+        auto field = [](const Json& o, const char* key, long maxv, long& v) {      // absent: 0; present: a whole number in [0, maxv], or the file is refused
+            const Json* j = o.get(key);
+            v = 0;
+            if (!j) return true;
+            if (j->kind != Json::Num || !(j->num >= 0.0 && j->num <= (double)maxv) || j->num != std::floor(j->num)) return false;
+            v = (long)j->num;
+            return true;
+        };
+        long off_v, off_a, stride_v;
+        if (!field(bv, "byteOffset", 1l << 40, off_v) || !field(a, "byteOffset", 1l << 40, off_a) || !field(bv, "byteStride", 1l << 31, stride_v)) return false;
+        const size_t off = (size_t)off_v + (size_t)off_a, elem = esz * (size_t)nc;
+        const size_t stride = stride_v ? (size_t)stride_v : elem;
         const std::vector<uint8_t>& B = buffers[buf];
-        if (A.count && (off > B.size() || (A.count - 1) * stride + elem > B.size() - off)) return false;
+        if (A.count && (off > B.size() || elem > B.size() - off || (A.count - 1) > (B.size() - off - elem) / stride)) return false;
         const Json* nrm = a.get("normalized");
         const bool normalized = nrm && nrm->kind == Json::Bool && nrm->b && ct != 5126;
         for (size_t i = 0; i < A.count; i++)
@@ -1527,11 +1575,29 @@ static int model_load_gltf_impl(const char* file, fovpt_model** out)
         if (ti >= 0 && (size_t)ti < jtex.arr.size()) {
             const long src = jtex.arr[ti].integer("source", -1);
             if (src >= 0 && (size_t)src < jimg.arr.size()) {
+                // an image is a file beside the scene, a data: URI, or a range of a buffer (the usual case in a .glb) -- tinygltf
+                // hands all three to stb_image; so do the decoders here
                 const Json* uri = jimg.arr[src].get("uri");
-                if (uri && uri->kind == Json::Str && uri->str.compare(0, 5, "data:") != 0) {
-                    Image img;
-                    if (load_texture_file(dir + uri->str, img)) { model->textures.push_back(std::move(img)); tid = (int)model->textures.size() - 1; }
+                const Json* view = jimg.arr[src].get("bufferView");
+                Image img;
+                bool ok = false;
+                if (uri && uri->kind == Json::Str) {
+                    if (uri->str.compare(0, 5, "data:") != 0) ok = load_texture_file(dir + uri->str, img);
+                    else {
+                        const size_t comma = uri->str.find(',');
+                        std::vector<uint8_t> blob;
+                        if (comma != std::string::npos && b64_decode(uri->str.substr(comma + 1), blob)) ok = decode_texture_bytes(blob, std::string(), img);
+                    }
+                } else if (view && view->kind == Json::Num && view->num >= 0 && (size_t)view->num < jviews.arr.size()) {
+                    const Json& bv = jviews.arr[(size_t)view->num];
+                    const long buf = bv.integer("buffer", -1), off = bv.integer("byteOffset", 0), len = bv.integer("byteLength", -1);
+                    if (buf >= 0 && (size_t)buf < buffers.size() && off >= 0 && len > 0 && (size_t)off <= buffers[buf].size()
+                        && (size_t)len <= buffers[buf].size() - (size_t)off) {
+                        const std::vector<uint8_t> blob(buffers[buf].begin() + off, buffers[buf].begin() + off + len);
+                        ok = decode_texture_bytes(blob, std::string(), img);
+                    }
                 }
+                if (ok) { model->textures.push_back(std::move(img)); tid = (int)model->textures.size() - 1; }
             }
         }
         tex_cache[ti] = tid;
@@ -1616,9 +1682,13 @@ static int model_load_gltf_impl(const char* file, fovpt_model** out)
                 if (jt && jt->kind == Json::Num) {
                     Acc tc;
                     if (!accessor((long)jt->num, false, tc) || tc.nc < 2) { failure = "bad TEXCOORD_0 accessor"; return; }
-                    mesh.texcoord.resize(tc.count);
-                    for (size_t i = 0; i < tc.count; i++) mesh.texcoord[i] = {tc.f[i * tc.nc], tc.f[i * tc.nc + 1]};
-                    has_tc = true;
+                    // (one texcoord per vertex, or none: a shorter array would be read past its end by whoever indexes it with a
+                    // vertex index -- fovpt_set_scene does)
+                    if (tc.count == pos.count) {
+                        mesh.texcoord.resize(tc.count);
+                        for (size_t i = 0; i < tc.count; i++) mesh.texcoord[i] = {tc.f[i * tc.nc], tc.f[i * tc.nc + 1]};
+                        has_tc = true;
+                    }
                 }
                 int tid = -1;
                 material(prim.get("material"), mesh.material, tid);

@@ -981,7 +981,7 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
         STEPSTAT(diag + 2);
         leaf_step<false>(sc, r, q, T CYC_A); nl++;
     }
-    T.steps = nn | (nl << 16);
+    T.steps = min(nn, 4095u) | (min(nl, 255u) << 12) | (min(T.n0, 63u) << 20);      // (bits 26-31: dropped pops of round 4's pruning experiment, tools/stepcount.py)
     T.tr_hi |= (unsigned long long)min(T.n0, 255u) << 56;
 #else
     for (;;) {

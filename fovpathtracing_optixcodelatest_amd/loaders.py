@@ -316,6 +316,15 @@ def _load_texture(path: str) -> Optional[np.ndarray]:
     try:
         with open(path, "rb") as f:
             data = f.read()
+    except OSError:
+        return None
+    return _decode_texture_bytes(data, path)
+
+
+def _decode_texture_bytes(data: bytes, path: str = "") -> Optional[np.ndarray]:
+    """The bytes of an image file (or of an image embedded in a glTF buffer / data URI: `path` empty) -> RGBA8 as (H, W)
+    uint32 mirrored along y, or None."""
+    try:
         if data[:8] == b"\x89PNG\r\n\x1a\n":
             rgba = decode_png(data)
         elif data[:2] == b"P6":
@@ -323,7 +332,14 @@ def _load_texture(path: str) -> Optional[np.ndarray]:
         elif path.lower().endswith(".tga"):
             rgba = decode_tga(data)
         elif data[:3] == b"\xff\xd8\xff":
-            rgba = decode_jpeg_native(path)
+            if path and os.path.exists(path):
+                rgba = decode_jpeg_native(path)
+            else:
+                import tempfile
+                with tempfile.NamedTemporaryFile(suffix=".jpg") as tmp:
+                    tmp.write(data)
+                    tmp.flush()
+                    rgba = decode_jpeg_native(tmp.name)
         else:
             return None
     except Exception:
@@ -868,12 +884,21 @@ def load_gltf(gltf_file: str) -> Model:
         tid = -1
         try:
             img = g["images"][g["textures"][tex_index]["source"]]
-            if "uri" in img and not img["uri"].startswith("data:"):
-                px = _load_texture(os.path.join(base, img["uri"]))
-                if px is not None:
-                    model.textures.append(px)
-                    tid = len(model.textures) - 1
-        except (KeyError, IndexError):
+            px = None
+            if "uri" in img:                         # a file beside the scene, or a data: URI
+                if not img["uri"].startswith("data:"):
+                    px = _load_texture(os.path.join(base, img["uri"]))
+                elif "," in img["uri"]:
+                    px = _decode_texture_bytes(base64.b64decode(img["uri"].split(",", 1)[1]))
+            elif "bufferView" in img:                # a range of a buffer: the usual case in a .glb
+                bv = g["bufferViews"][img["bufferView"]]
+                off, n, blob = bv.get("byteOffset", 0), bv.get("byteLength", -1), buffers[bv["buffer"]]
+                if 0 <= off <= len(blob) and 0 < n <= len(blob) - off:
+                    px = _decode_texture_bytes(bytes(blob[off:off + n]))
+            if px is not None:
+                model.textures.append(px)
+                tid = len(model.textures) - 1
+        except (KeyError, IndexError, TypeError):
             tid = -1
         tex_cache[tex_index] = tid
         return tid
@@ -929,6 +954,8 @@ def load_gltf(gltf_file: str) -> Model:
                 tc = None
                 if "TEXCOORD_0" in prim["attributes"]:
                     tc = np.ascontiguousarray(accessor(prim["attributes"]["TEXCOORD_0"]).astype(np.float32)[:, :2])
+                    if tc.shape[0] != pos.shape[0]:        # one texcoord per vertex, or none (as the library's loader)
+                        tc = None
                 mat, tid = material(prim.get("material"))
                 model.meshes.append(TriangleMesh(vertex=np.ascontiguousarray(world), index=np.ascontiguousarray(idx), material=mat,
                                                  texcoord=tc, texture_id=tid if tc is not None else -1))

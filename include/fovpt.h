@@ -168,7 +168,9 @@ typedef struct fovpt_config {
                                    generate, closest hit, shade, one after the other -- may run BESIDE each other:
                                    0 = the library's default (2), 1 = one frame at a time (lowest latency per frame),
                                    2 = two (highest throughput: each chain fills the other's gaps; a frame then takes
-                                   about twice as long from first to last kernel).  Results do not depend on it: resolves
+                                   about twice as long from first to last kernel); 3 and 4 are accepted and measured slower
+                                   than 2 (a context has FOVPT_LANES = 2 stream pairs unless the environment says more; a
+                                   larger value means all of them).  Results do not depend on it: resolves
                                    run in issue order, and fovpt_stream() is ordered behind every finished frame.        */
     int32_t chains_per_frame;   /* 0 / 1 = a frame is one chain of dependent launches; 2 = every frame is rendered as TWO
                                    independent chains over halves of its sample slots (each with four of the eight queue

@@ -423,6 +423,127 @@ def test_oversized_image_headers_under_asan(tmp_path):
             assert "rc=0" not in out[n], out[n]
 
 
+def test_malformed_jpeg_and_gltf_under_asan(tmp_path):
+    """ADVICE r3 (high, medium): the JPEG decoder and the glTF reader of the library on files that lie -- sampling factors that
+    do not divide the largest one (the heap overflow the advisor reproduced; the reference's vendored stb_image has it too),
+    truncated scans, a progressive file without its Huffman tables, huge dimensions, random byte damage; accessors whose
+    stride / offset / count wrap 64 bits or run past their buffer, TEXCOORD_0 shorter than POSITION, images embedded through a
+    bufferView or a data: URI with ranges outside their buffer.  Compiled with AddressSanitizer: any out-of-bounds access
+    fails the test; a file is refused or decoded, never read past."""
+    import base64, json, struct, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "loader_asan"
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer", "-ffp-contract=off",
+                           os.path.join(root, "fovpathtracing_optixcodelatest_amd", "csrc", "model_loader.cpp"),
+                           os.path.join(root, "tests", "cpp", "loader_asan_main.cpp"), "-lz", "-o", str(exe)])
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_jpeg.npz"))
+    names = sorted(k[5:] for k in z.files if k.startswith("file:"))
+    base = z["file:" + [n for n in names if n.startswith("base_50x41_s2")][0]].tobytes()
+    prog = z["file:" + [n for n in names if n.startswith("prog_40x24_s2")][0]].tobytes()
+    files, must_fail, must_load = {}, set(), set()
+
+    def sof(data, marker=b"\xff\xc0"):
+        return data.index(marker)
+    # (1) fractional sampling: Y 3x1, Cb 2x1, Cr 1x1 on a wide image (ADVICE's file), and the vertical twin
+    i = sof(base)
+    for tag, samp, dims in (("h", (0x31, 0x21, 0x11), (8, 2400)), ("v", (0x13, 0x12, 0x11), (2400, 8))):
+        b = bytearray(base)
+        b[i + 5:i + 9] = struct.pack(">HH", *dims)
+        for c in range(3):
+            b[i + 11 + 3 * c] = samp[c]
+        files["frac_%s.jpg" % tag] = bytes(b); must_fail.add("frac_%s.jpg" % tag)
+    # (2) truncated scans: cut inside the entropy-coded data at many places (refused: no EOI; never read past)
+    for k, cut in enumerate(np.linspace(len(base) // 3, len(base) - 3, 12).astype(int)):
+        files["cut_%02d.jpg" % k] = base[:cut]; must_fail.add("cut_%02d.jpg" % k)
+    # (3) a progressive file whose DHT segments are gone
+    b, pos = bytearray(), 0
+    while pos < len(prog):
+        if prog[pos:pos + 2] == b"\xff\xc4":
+            pos += 2 + struct.unpack(">H", prog[pos + 2:pos + 4])[0]
+            continue
+        if prog[pos:pos + 2] == b"\xff\xda":
+            b += prog[pos:]
+            break
+        b.append(prog[pos]); pos += 1
+    files["prog_no_tables.jpg"] = bytes(b); must_fail.add("prog_no_tables.jpg")
+    # (4) dimensions: 65535 x 65535 is over the pixel budget; 4000 x 3000 over a 50 x 41 scan decodes (the missing blocks are
+    # whatever zeros decode to) or is refused, without touching memory it does not own
+    i = sof(base)
+    for tag, dims in (("huge", (65535, 65535)), ("big", (3000, 4000)), ("zero", (0, 16))):
+        b = bytearray(base); b[i + 5:i + 9] = struct.pack(">HH", *dims); files["dims_%s.jpg" % tag] = bytes(b)
+    must_fail |= {"dims_huge.jpg", "dims_zero.jpg"}
+    # (5) random damage, baseline and progressive
+    rng = np.random.default_rng(5)
+    for k in range(60):
+        src = bytearray(base if k % 2 == 0 else prog)
+        for _ in range(int(rng.integers(1, 6))):
+            src[int(rng.integers(2, len(src)))] = int(rng.integers(0, 256))
+        files["damage_%02d.jpg" % k] = bytes(src)
+    files["ok.jpg"] = base; must_load.add("ok.jpg")
+
+    # glTF: one triangle, positions + texcoords + indices in one buffer, a PNG embedded behind them
+    from fovpathtracing_optixcodelatest_amd import loaders as _l
+    pos3 = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0]], np.float32).tobytes()
+    tc2 = np.array([[0, 0], [1, 0], [0, 1]], np.float32).tobytes()
+    idx = np.array([0, 1, 2], np.uint16).tobytes() + b"\0\0"
+    png = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gltf_fixture", "checker.png"), "rb").read() \
+        if os.path.exists(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gltf_fixture", "checker.png")) else None
+    if png is None:
+        import zlib
+        def chunk(kind, body):
+            return struct.pack(">I", len(body)) + kind + body + struct.pack(">I", zlib.crc32(kind + body) & 0xffffffff)
+        rows = b"".join(b"\0" + bytes([(37 * (x + 3 * y)) & 255 for x in range(4) for _ in range(3)]) for y in range(4))
+        png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 4, 4, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(rows)) + chunk(b"IEND", b"")
+    blob = pos3 + tc2 + idx + png
+    o_tc, o_idx, o_png = len(pos3), len(pos3) + len(tc2), len(pos3) + len(tc2) + len(idx)
+
+    def gltf(acc_pos=None, acc_tc=None, view_extra=None, image=None, acc_idx=None):
+        views = [{"buffer": 0, "byteOffset": 0, "byteLength": len(pos3)}, {"buffer": 0, "byteOffset": o_tc, "byteLength": len(tc2)},
+                 {"buffer": 0, "byteOffset": o_idx, "byteLength": 6}, {"buffer": 0, "byteOffset": o_png, "byteLength": len(png)}]
+        if view_extra:
+            views[view_extra[0]].update(view_extra[1])
+        a_pos = {"bufferView": 0, "componentType": 5126, "count": 3, "type": "VEC3"}; a_pos.update(acc_pos or {})
+        a_tc = {"bufferView": 1, "componentType": 5126, "count": 3, "type": "VEC2"}; a_tc.update(acc_tc or {})
+        a_idx = {"bufferView": 2, "componentType": 5123, "count": 3, "type": "SCALAR"}; a_idx.update(acc_idx or {})
+        return json.dumps({"asset": {"version": "2.0"}, "buffers": [{"byteLength": len(blob), "uri": "data:application/octet-stream;base64," + base64.b64encode(blob).decode()}],
+                           "bufferViews": views, "accessors": [a_pos, a_tc, a_idx],
+                           "images": [image if image is not None else {"bufferView": 3, "mimeType": "image/png"}], "textures": [{"source": 0}],
+                           "materials": [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}],
+                           "meshes": [{"primitives": [{"attributes": {"POSITION": 0, "TEXCOORD_0": 1}, "indices": 2, "material": 0}]}],
+                           "nodes": [{"mesh": 0}], "scenes": [{"nodes": [0]}], "scene": 0}).encode()
+    files["ok.gltf"] = gltf(); must_load.add("ok.gltf")
+    files["ok_datauri_image.gltf"] = gltf(image={"uri": "data:image/png;base64," + base64.b64encode(png).decode()}); must_load.add("ok_datauri_image.gltf")
+    files["stride_2p62.gltf"] = gltf(view_extra=(0, {"byteStride": 2 ** 62}), acc_pos={"count": 5}); must_fail.add("stride_2p62.gltf")
+    files["stride_wrap.gltf"] = gltf(view_extra=(0, {"byteStride": 2 ** 31}), acc_pos={"count": 2 ** 28}); must_fail.add("stride_wrap.gltf")
+    files["offset_2p63.gltf"] = gltf(acc_pos={"byteOffset": 2 ** 63}); must_fail.add("offset_2p63.gltf")
+    files["offset_neg.gltf"] = gltf(acc_pos={"byteOffset": -8}); must_fail.add("offset_neg.gltf")
+    files["offset_nan.gltf"] = gltf().replace(b'"byteOffset": 0, "byteLength": %d' % len(pos3), b'"byteOffset": 1e999, "byteLength": %d' % len(pos3)); must_fail.add("offset_nan.gltf")
+    files["count_past_end.gltf"] = gltf(acc_pos={"count": 10 ** 6}); must_fail.add("count_past_end.gltf")
+    files["short_texcoords.gltf"] = gltf(acc_tc={"count": 1}); must_load.add("short_texcoords.gltf")        # loads WITHOUT texcoords (and so without its texture)
+    files["index_past_end.gltf"] = gltf(acc_idx={"count": 3000}); must_fail.add("index_past_end.gltf")
+    files["image_view_past_end.gltf"] = gltf(view_extra=(3, {"byteLength": 10 ** 9})); must_load.add("image_view_past_end.gltf")   # texture id -1
+    files["image_view_neg.gltf"] = gltf(view_extra=(3, {"byteOffset": -5})); must_load.add("image_view_neg.gltf")
+    for n, b in files.items():
+        (tmp_path / n).write_bytes(b)
+    names = sorted(files)
+    res = subprocess.run([str(exe)] + [str(tmp_path / n) for n in names], capture_output=True, text=True,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0:allocator_may_return_null=1"))
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = {os.path.basename(l.split()[0]): l for l in res.stdout.splitlines()}
+    assert len(out) == len(names), res.stdout
+    for n in must_fail:
+        assert "rc=0" not in out[n], out[n]
+    for n in must_load:
+        assert "rc=0" in out[n], out[n]
+    assert "meshes=1 textures=1" in out["ok.gltf"] and "meshes=1 textures=1" in out["ok_datauri_image.gltf"], (out["ok.gltf"], out["ok_datauri_image.gltf"])
+    assert "textures=0" in out["image_view_past_end.gltf"] and "textures=0" in out["image_view_neg.gltf"]
+    # the python loader takes the same decisions on the well-formed ones
+    for n in ("ok.gltf", "ok_datauri_image.gltf", "short_texcoords.gltf"):
+        a, b = _l.load_gltf(str(tmp_path / n)), _l.load_gltf_native(str(tmp_path / n))
+        _same_model(a, b)
+        assert (a.meshes[0].texcoord is None) == (n == "short_texcoords.gltf")
+
+
 def _same_model(a, b):
     assert len(a.meshes) == len(b.meshes) and len(a.textures) == len(b.textures)
     for x, y in zip(a.meshes, b.meshes):

@@ -12,7 +12,7 @@ NODE, LEAF = 34.0, 48.0
 def load(path):
     z = np.load(path)
     st, tr = z["steps"], z["trace"].astype(np.int32)
-    nn, nl = (st & 0xffff).astype(np.int32), (st >> 16).astype(np.int32)
+    nn, nl = (st & 0xfff).astype(np.int32), ((st >> 12) & 0xff).astype(np.int32)
     ok = nl < 16
     # phases: nl+1 node phases (the last one ends the traversal)
     return nn, nl, tr, ok

@@ -31,9 +31,9 @@ qo = buf("queue_b_o", np.float32).reshape(-1, 4); qd = buf("queue_b_d", np.float
 sel = np.concatenate([np.arange(s * cap, s * cap + n1[s]) for s in range(8)])
 slots = qo[sel, 3].view(np.uint32)
 st = qd[sel, 3].view(np.uint32)                  # node | leaf << 16 steps, written by the STEPSTAT traversal
-steps = (st & 0xffff) + 2.7 * (st >> 16)         # a leaf step costs about 2.7 node steps
+steps = (st & 0xfff) + 2.7 * ((st >> 12) & 0xff)         # a leaf step costs about 2.7 node steps
 d = qd[sel, :3]; o = qo[sel, :3]
-print("bounce-1 rays:", slots.size, "mean cost %.1f" % steps.mean(), "node %.1f leaf %.2f" % ((st & 0xffff).mean(), (st >> 16).mean()))
+print("bounce-1 rays:", slots.size, "mean cost %.1f" % steps.mean(), "node %.2f leaf %.2f no-hit steps %.2f skipped pops %.2f" % ((st & 0xfff).mean(), ((st >> 12) & 0xff).mean(), ((st >> 20) & 63).mean(), (st >> 26).mean()))
 def wave_cost(order, label):
     s = steps[order]
     n = s.size // 16 * 16

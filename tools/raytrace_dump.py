@@ -37,7 +37,7 @@ tr = buf("trace", np.uint8).reshape(-1, 16)
 hit = buf("hit", np.float32).reshape(-1, 4)
 sel = np.concatenate([np.arange(s * cap, s * cap + nq[s]) for s in range(8)])
 st = qd[sel, 3].view(np.uint32)
-print("bounce", B, "rays", sel.size, "node %.2f leaf %.2f" % ((st & 0xffff).mean(), (st >> 16).mean()), "miss frac %.3f" % (hit[sel, 3].view(np.uint32) == 0xffffffff).mean())
+print("bounce", B, "rays", sel.size, "node %.2f leaf %.2f no-hit %.2f skipped %.2f" % ((st & 0xfff).mean(), ((st >> 12) & 0xff).mean(), ((st >> 20) & 63).mean(), (st >> 26).mean()), "miss frac %.3f" % (hit[sel, 3].view(np.uint32) == 0xffffffff).mean())
 os.makedirs("gpurun_out", exist_ok=True)
 np.savez_compressed("gpurun_out/raytrace_b%d_%d.npz" % (B, ntri), steps=st, trace=tr[sel], shard_sizes=nq, miss=(hit[sel, 3].view(np.uint32) == 0xffffffff),
                     o=qo[sel, :3].astype(np.float32), d=qd[sel, :3].astype(np.float16), t=hit[sel, 0].astype(np.float32))
