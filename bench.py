@@ -214,7 +214,9 @@ def main():
     ap.add_argument("--no-variants", action="store_true", help="skip the HDR-probe / moving-camera / 1 M / 3.8 M-triangle variants")
     ap.add_argument("--frames-in-flight", type=int, default=0, choices=(0, 1, 2),
                     help="fovpt_config.frames_in_flight for the timed region: 0 = the library's default (2), 1 = one frame at a time")
-    ap.add_argument("--gather", choices=("packed", "reduce"), default="packed", help="N > 1: packed owned-pixel gather (default) or full-frame sum-reduce")
+    ap.add_argument("--gather", choices=("packed", "reduce", "lib"), default="packed",
+                    help="N > 1: packed owned-pixel gather through torch.distributed (default), full-frame sum-reduce, or `lib`: the library's OWN "
+                         "RCCL transport (fovpt_comm_init / fovpt_gather_frame, what a C++ host uses; also runs at N = 1 as a group of one)")
     ap.add_argument("--advance-subframe", action="store_true",
                     help="let render() advance subframe_index from frame to frame (new P-pass seeds every frame) instead of "
                          "resetting it to 0 as the shipped application does (main.cpp:402-407)")
@@ -275,6 +277,17 @@ def main():
     pending = [None] * nbuf
     step_no = [0]
     packed = args.gather == "packed" and world > 1
+    lib_gather = args.gather == "lib"
+    if lib_gather:
+        # the communicator of the library itself: rank 0 makes the unique id, the existing process group carries it to the others
+        if rehearsal and world > 1:
+            raise SystemExit("--gather lib needs one GPU per rank: RCCL refuses two ranks of one communicator on one device")
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid = torch.tensor(list(renderer.SampleRenderer.comm_unique_id()), dtype=torch.uint8, device="cuda")
+        if world > 1:
+            dist.broadcast(uid, src=0)
+        r.comm_init(bytes(uid.cpu().tolist()), rank, world)
     pg = None
     if packed:
         pg = multigpu.PackedGather(r, dev, dst=0, nbuffers=nbuf)
@@ -304,7 +317,11 @@ def main():
                 r.launchParams.frame.subframe_index = 0
             r.launchParams.frame.frame_buffer = frames[k].data_ptr()
             r.render_async()
-            if world > 1:
+            if lib_gather:
+                # plan -> pack -> ncclSend / ncclRecv -> unpack, all queued by the library on its own completion stream: nothing to wait
+                # for here; rank 0 gathers into the frame it rendered into
+                r.gather_frame(0, frames[k].data_ptr(), frames[k].data_ptr() if rank == 0 else None)
+            elif world > 1:
                 if packed:
                     pending[k] = pg.gather(frames[k], k, async_op=True) or "sync"
                 elif rehearsal:                                # gloo knows nothing about HIP streams
@@ -324,7 +341,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world == 1:
+    if lib_gather:
+        gather_mode = "the library's own transport: fovpt_gather_frame = HIP pack -> ncclSend / ncclRecv (librccl, group of %d) -> HIP unpack on rank 0, on fovpt_stream()" % world
+    elif world == 1:
         gather_mode = "none"
     elif packed:
         gather_mode = "packed owned pixels: HIP pack -> %s gather -> HIP unpack on rank 0, %d B per rank (full frame %d B)" % (

@@ -310,9 +310,9 @@ __device__ inline float box_area(const Box& b);
 //     gain(y) = G_k - inc(y) - A(x u y),   G_k = A(p) + what the path's nodes below level k shrink by,
 //     inc(y)  = what y's ancestors inside that subtree grow by,          and below y no gain exceeds G_k - inc'(y) - A(x).
 // Moves conflict when they touch the same nodes; every move stamps (gain, x) with atomicMax on the six nodes whose links it
-// rewrites (x, p, s, p's parent, y, y's parent) and on the ancestors of y below the search level (so that two subtrees cannot
-// be moved into each other), and only a move that still owns all its stamps is carried out.  Then the boxes are refitted and
-// the next round starts.  The tree's shape changes, the set of triangles below the root does not, and no shape changes a
+// rewrites (x, p, s, p's parent, y, y's parent), only a move that still owns all its stamps survives, and of two survivors that
+// would move their subtrees into each other one yields (k_reinsert_check2).  Then the boxes are refitted and the next round
+// starts.  The tree's shape changes, the set of triangles below the root does not, and no shape changes a
 // result (include/fovpt.h) -- only the node steps per ray.
 // ------------------------------------------------------------------------------------------
 struct TreeView {
@@ -331,7 +331,10 @@ struct Move { int out; int pivot; float gain; };
 
 #define FOVPT_REINSERT_STACK 96
 #ifndef FOVPT_REINSERT_DEFAULT
-#define FOVPT_REINSERT_DEFAULT 0
+#define FOVPT_REINSERT_DEFAULT 12          // at most this many rounds; a round that lowers the cost by less than FOVPT_REINSERT_STOP ends them
+#endif
+#ifndef FOVPT_REINSERT_STOP
+#define FOVPT_REINSERT_STOP 0.0015f
 #endif
 __global__ void k_reinsert_find(TreeView T, int root, Move* __restrict__ moves, uint32_t phase, uint32_t phases)
 {
@@ -392,50 +395,65 @@ __global__ void k_reinsert_find(TreeView T, int root, Move* __restrict__ moves, 
     moves[x] = mv;
 }
 
-// the nodes a move touches: x, p, s, q = parent(p), y, parent(y) and y's further ancestors below the search level
+// The six nodes whose links a move rewrites: x, p, s, q = parent(p), y, parent(y).  Two moves that share one of them conflict; the
+// larger (gain, x) stamp wins all six or the move is dropped.
 template <typename F> __device__ inline void reinsert_touch(const TreeView& T, int c, const Move& mv, F&& f)
 {
     const int p = T.parent(c), q = T.parent_int[p];
     const int s = T.left[p] == c ? T.right[p] : T.left[p];
-    f(T.slot(c)); f(T.slot(p)); f(T.slot(s)); f(T.slot(q)); f(T.slot(mv.out));
-    int a = T.parent(mv.out);
-    f(T.slot(a));                                     // y's parent gets a new child: owned even when it is the search level's node itself
-    while (a != mv.pivot) {
-        a = T.parent_int[a];
-        if (a < 0 || a == mv.pivot) break;
-        f(T.slot(a));
-    }
+    f(T.slot(c)); f(T.slot(p)); f(T.slot(s)); f(T.slot(q)); f(T.slot(mv.out)); f(T.slot(T.parent(mv.out)));
 }
-__global__ void k_reinsert_lock(TreeView T, const Move* __restrict__ moves, unsigned long long* __restrict__ lock)
+__device__ inline unsigned long long move_key(const Move& mv, uint32_t x) { return ((unsigned long long)__float_as_uint(mv.gain) << 32) | (unsigned long long)x; }
+__global__ void k_reinsert_lock(TreeView T, const Move* __restrict__ moves, unsigned long long* __restrict__ lock, uint32_t* __restrict__ counts)
 {
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= (uint32_t)(2 * T.n - 1)) return;
     const Move mv = moves[x];
     if (mv.pivot < 0) return;
     const int c = x < (uint32_t)(T.n - 1) ? (int)x : ~(int)(x - (uint32_t)(T.n - 1));
-    const unsigned long long key = ((unsigned long long)__float_as_uint(mv.gain) << 32) | (unsigned long long)x;
+    const unsigned long long key = move_key(mv, x);
     reinsert_touch(T, c, mv, [&](uint32_t i) { atomicMax(&lock[i], key); });
+    atomicAdd(&counts[2], 1u);                         // candidates (diagnostics)
 }
-__global__ void k_reinsert_check(TreeView T, Move* __restrict__ moves, const unsigned long long* __restrict__ lock, uint32_t* __restrict__ applied)
+// first check: the move owns its six nodes.  A survivor marks the node it moves.
+__global__ void k_reinsert_check(TreeView T, Move* __restrict__ moves, const unsigned long long* __restrict__ lock, unsigned char* __restrict__ moving)
 {
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= (uint32_t)(2 * T.n - 1)) return;
     Move mv = moves[x];
     if (mv.pivot < 0) return;
     const int c = x < (uint32_t)(T.n - 1) ? (int)x : ~(int)(x - (uint32_t)(T.n - 1));
-    const unsigned long long key = ((unsigned long long)__float_as_uint(mv.gain) << 32) | (unsigned long long)x;
+    const unsigned long long key = move_key(mv, x);
     bool mine = true;
     reinsert_touch(T, c, mv, [&](uint32_t i) { if (lock[i] != key) mine = false; });
     if (!mine) { mv.pivot = -1; moves[x] = mv; }
-    else atomicAdd(applied, 1u);
+    else moving[x] = 1;
 }
-__device__ inline void set_parent(const TreeView& T, int c, int p) { if (c < 0) T.parent_leaf[~c] = p; else T.parent_int[c] = p; }
-__global__ void k_reinsert_apply(TreeView T, const Move* __restrict__ moves)
+// second check: two subtrees must not be moved INTO each other (x_A below an ancestor that move B carries off into x_A's own
+// subtree would close a cycle).  A survivor whose target y has, below the search level, an ancestor that another survivor moves
+// yields when that move's stamp is the larger one: in any such ring the move in front of the largest stamp yields, so no ring
+// survives.  (`moving` and `lock` are only read here; the verdict goes into its own array.)
+__global__ void k_reinsert_check2(TreeView T, const Move* __restrict__ moves, const unsigned long long* __restrict__ lock,
+                                  const unsigned char* __restrict__ moving, unsigned char* __restrict__ yield, uint32_t* __restrict__ counts)
 {
     const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
     if (x >= (uint32_t)(2 * T.n - 1)) return;
     const Move mv = moves[x];
     if (mv.pivot < 0) return;
+    const unsigned long long key = move_key(mv, x);
+    bool y = false;
+    for (int a = T.parent(mv.out); a >= 0 && a != mv.pivot; a = T.parent_int[a])
+        if (moving[T.slot(a)] && lock[T.slot(a)] > key) { y = true; break; }      // (a survivor owns the stamp of the node it moves)
+    yield[x] = y ? 1 : 0;
+    if (!y) atomicAdd(&counts[0], 1u);
+}
+__device__ inline void set_parent(const TreeView& T, int c, int p) { if (c < 0) T.parent_leaf[~c] = p; else T.parent_int[c] = p; }
+__global__ void k_reinsert_apply(TreeView T, const Move* __restrict__ moves, const unsigned char* __restrict__ yield)
+{
+    const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= (uint32_t)(2 * T.n - 1)) return;
+    const Move mv = moves[x];
+    if (mv.pivot < 0 || yield[x]) return;
     // every link written here belongs to a node this move owns (k_reinsert_check), and no other surviving move reads it
     const int c = x < (uint32_t)(T.n - 1) ? (int)x : ~(int)(x - (uint32_t)(T.n - 1));
     const int p = T.parent(c), q = T.parent_int[p];
@@ -885,7 +903,8 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
     bool tree_changed = false;
     Move* re_moves = nullptr;
     unsigned long long* re_lock = nullptr;
-    uint32_t *re_arrive = nullptr, *re_scalars = nullptr;
+    uint32_t *re_arrive = nullptr, *re_scalars = nullptr;      // re_scalars: [0] moves applied, [1] sum of internal areas (float), [2] candidates
+    unsigned char* re_flags = nullptr;                         // [0, nall): the node is moved by a surviving move; [nall, 2 nall): the move yields
     uint32_t* dp_arrive = nullptr;
     uint32_t* counters = nullptr;
     BvhNode4* nodes = nullptr;
@@ -1019,33 +1038,38 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
                 HC(hipMalloc(&re_moves, sizeof(Move) * (size_t)nall));
                 HC(hipMalloc(&re_lock, 8ull * nall));
                 HC(hipMalloc(&re_arrive, 4ull * ni));
-                HC(hipMalloc(&re_scalars, 8));
-                float cost0 = 0.f;
-                if (verbose) {
-                    HC(hipMemsetAsync(re_arrive, 0, 4ull * ni, st)); HC(hipMemsetAsync(re_scalars, 0, 8, st));
-                    hipLaunchKernelGGL(k_tree_refit, dim3(gn), dim3(B), 0, st, T, size_int, side_int, side_leaf, re_arrive, (float*)(re_scalars + 1));
-                    HC(hipMemcpyAsync(&cost0, re_scalars + 1, 4, hipMemcpyDeviceToHost, st));
-                    HC(hipStreamSynchronize(st));
-                    fprintf(stderr, "[fovpt bvh] PLOC tree: sum of internal areas %.6g\n", (double)cost0);
-                }
+                HC(hipMalloc(&re_scalars, 16));
+                HC(hipMalloc(&re_flags, 2ull * nall));
+                // the cost of the tree as PLOC left it (what the first round's gain is measured against)
+                float cost_prev = 0.f;
+                HC(hipMemsetAsync(re_arrive, 0, 4ull * ni, st)); HC(hipMemsetAsync(re_scalars, 0, 16, st));
+                hipLaunchKernelGGL(k_tree_refit, dim3(gn), dim3(B), 0, st, T, size_int, side_int, side_leaf, re_arrive, (float*)(re_scalars + 1));
+                HC(hipMemcpyAsync(&cost_prev, re_scalars + 1, 4, hipMemcpyDeviceToHost, st));
+                HC(hipStreamSynchronize(st));
+                if (verbose) fprintf(stderr, "[fovpt bvh] PLOC tree: sum of internal areas %.6g\n", (double)cost_prev);
                 for (int round = 0; round < reinsert_rounds; round++) {
                     uint32_t applied = 0;
                     float cost = 0.f;
                     hipLaunchKernelGGL(k_reinsert_find, dim3(gall2), dim3(B), 0, st, T, (int)n - 2, re_moves, 0u, 1u);
                     HC(hipMemsetAsync(re_lock, 0, 8ull * nall, st));
-                    hipLaunchKernelGGL(k_reinsert_lock, dim3(gall2), dim3(B), 0, st, T, re_moves, re_lock);
-                    HC(hipMemsetAsync(re_scalars, 0, 8, st));
-                    hipLaunchKernelGGL(k_reinsert_check, dim3(gall2), dim3(B), 0, st, T, re_moves, re_lock, re_scalars);
-                    hipLaunchKernelGGL(k_reinsert_apply, dim3(gall2), dim3(B), 0, st, T, re_moves);
+                    HC(hipMemsetAsync(re_flags, 0, 2ull * nall, st));
+                    HC(hipMemsetAsync(re_scalars, 0, 16, st));
+                    hipLaunchKernelGGL(k_reinsert_lock, dim3(gall2), dim3(B), 0, st, T, re_moves, re_lock, re_scalars);
+                    hipLaunchKernelGGL(k_reinsert_check, dim3(gall2), dim3(B), 0, st, T, re_moves, re_lock, re_flags);
+                    hipLaunchKernelGGL(k_reinsert_check2, dim3(gall2), dim3(B), 0, st, T, re_moves, re_lock, re_flags, re_flags + nall, re_scalars);
+                    hipLaunchKernelGGL(k_reinsert_apply, dim3(gall2), dim3(B), 0, st, T, re_moves, re_flags + nall);
                     HC(hipMemsetAsync(re_arrive, 0, 4ull * ni, st));
                     hipLaunchKernelGGL(k_tree_refit, dim3(gn), dim3(B), 0, st, T, size_int, side_int, side_leaf, re_arrive, (float*)(re_scalars + 1));
+                    uint32_t candidates = 0;
                     HC(hipMemcpyAsync(&applied, re_scalars, 4, hipMemcpyDeviceToHost, st));
                     HC(hipMemcpyAsync(&cost, re_scalars + 1, 4, hipMemcpyDeviceToHost, st));
+                    HC(hipMemcpyAsync(&candidates, re_scalars + 2, 4, hipMemcpyDeviceToHost, st));
                     HC(hipStreamSynchronize(st));
                     HC(hipGetLastError());
                     tree_changed = tree_changed || applied > 0;
-                    if (verbose) fprintf(stderr, "[fovpt bvh] reinsertion round %d: %u moves, sum of internal areas %.6g\n", round, applied, (double)cost);
-                    if ((uint64_t)applied * 2000u < n) break;                      // (nothing much left to gain)
+                    if (verbose) fprintf(stderr, "[fovpt bvh] reinsertion round %d: %u of %u candidate moves, sum of internal areas %.6g\n", round, applied, candidates, (double)cost);
+                    if (applied == 0 || !(cost_prev - cost > FOVPT_REINSERT_STOP * cost_prev)) break;      // (nothing much left to gain)
+                    cost_prev = cost;
                 }
             }
             const uint32_t gall = (2 * n - 1 + B - 1) / B;
@@ -1138,7 +1162,7 @@ fail:
     (void)hipFree(c_node); (void)hipFree(t_node); (void)hipFree(nn); (void)hipFree(c_box); (void)hipFree(t_box); (void)hipFree(valid); (void)hipFree(pos);
     (void)hipFree(node_counter); (void)hipFree(size_int); (void)hipFree(leaf_pos); (void)hipFree(node_first); (void)hipFree(node_depth);
     (void)hipFree(dp); (void)hipFree(dp_arrive); (void)hipFree(order_pc);
-    (void)hipFree(re_moves); (void)hipFree(re_lock); (void)hipFree(re_arrive); (void)hipFree(re_scalars);
+    (void)hipFree(re_moves); (void)hipFree(re_lock); (void)hipFree(re_arrive); (void)hipFree(re_scalars); (void)hipFree(re_flags);
     (void)hipFree(side_int); (void)hipFree(side_leaf); (void)hipFree(scan_temp); (void)hipFree(work_a); (void)hipFree(work_b); (void)hipFree(counters);
     return rc;
 }

@@ -130,7 +130,47 @@ def load():
     return L
 
 
-def check(ctx, rc):
+LOADER_SO_PATH = os.path.join(CSRC, "libfovpt_loader.so")
+LOADER_EXPORTS = [n for n in EXPORTS if n.startswith("fovpt_model_") or n.startswith("fovpt_image_")] + ["fovpt_last_error"]
+_loader = None
+
+
+def load_loader():
+    """The scene / image ingestion of the C ABI (fovpt_model_*, fovpt_image_*).  If libfovpt.so is already loaded, it; otherwise the
+    HOST-ONLY libfovpt_loader.so (same code, g++, no HIP runtime), so that reading OBJ / glTF / JPEG / HDR files needs no GPU
+    stack; FOVPT_SO (an A/B build of the whole library) takes precedence.  The render path never goes through here."""
+    global _loader
+    if _lib is not None or os.environ.get("FOVPT_SO") or not os.path.exists(LOADER_SO_PATH):
+        return load()
+    if _loader is not None:
+        return _loader
+    L = C.CDLL(LOADER_SO_PATH)
+    vp, i32 = C.c_void_p, C.c_int
+    L.fovpt_last_error.argtypes = [vp]
+    L.fovpt_last_error.restype = C.c_char_p
+    L.fovpt_model_load_obj.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.fovpt_model_load_gltf.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.fovpt_model_destroy.argtypes = [vp]
+    L.fovpt_model_destroy.restype = None
+    L.fovpt_model_counts.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
+    L.fovpt_model_get_mesh.argtypes = [vp, i32, C.POINTER(abi.ModelMesh)]
+    L.fovpt_model_get_texture.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32)]
+    L.fovpt_image_load_float4.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(vp)]
+    L.fovpt_image_free.argtypes = [vp]
+    L.fovpt_image_free.restype = None
+    L.fovpt_image_load_rgba8.argtypes = [C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(vp)]
+    L.fovpt_image_free_rgba8.argtypes = [vp]
+    L.fovpt_image_free_rgba8.restype = None
+    for name in LOADER_EXPORTS:
+        if name not in ("fovpt_last_error", "fovpt_model_destroy", "fovpt_image_free", "fovpt_image_free_rgba8"):
+            getattr(L, name).restype = i32
+    _loader = L
+    return L
+
+
+def check(ctx, rc, L=None):
+    """Raises FovptError with the library's text; `L`: the library the failing call was made in (the loader library keeps its own
+    error text)."""
     if rc != 0:
-        msg = load().fovpt_last_error(ctx)
+        msg = (L or load()).fovpt_last_error(ctx)
         raise FovptError(rc, msg.decode("utf-8", "replace") if msg else "")

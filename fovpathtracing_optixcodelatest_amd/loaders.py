@@ -296,9 +296,9 @@ def decode_jpeg_native(path: str) -> np.ndarray:
     """(H, W, 4) uint8 as stbi_load(path, ..., 4) returns it, through the library's host-side decoder (no GPU needed)."""
     import ctypes as C
     from . import lib
-    L = lib.load()
+    L = lib.load_loader()
     w, h, px = C.c_int32(0), C.c_int32(0), C.c_void_p()
-    lib.check(None, L.fovpt_image_load_rgba8(os.fsencode(path), C.byref(w), C.byref(h), C.byref(px)))
+    lib.check(None, L.fovpt_image_load_rgba8(os.fsencode(path), C.byref(w), C.byref(h), C.byref(px)), L)
     try:
         words = np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_uint32)), (h.value, w.value)).copy()
     finally:
@@ -309,8 +309,11 @@ def decode_jpeg_native(path: str) -> np.ndarray:
 def _load_texture(path: str) -> Optional[np.ndarray]:
     """RGBA8 as (H, W) uint32, mirrored along y (Model.cpp:117-126).  PNG, TGA and binary PPM are decoded
     here; JPEG by the library's host-side decoder (fovpt_image_load_rgba8: stb_image's inverse DCT, chroma
-    interpolation and colour conversion, bit for bit -- Pillow's libjpeg would give other pixels); anything
-    else counts as "could not load" (texture id -1, Model.cpp:129-131)."""
+    interpolation and colour conversion, bit for bit -- Pillow's libjpeg would give other pixels; the decoder is also
+    built as the host-only csrc/libfovpt_loader.so, so this needs no HIP runtime); anything else counts as "could not
+    load" (texture id -1, Model.cpp:129-131).  Of the formats the reference's stb_image reads, BMP, GIF, PSD, PIC and PNM
+    other than binary P6 are NOT decoded here or in the library (no pinned decoder exists for them; the reference's scenes use
+    TGA, PNG and JPEG): such a texture is id -1, which a caller sees as an untextured mesh."""
     if not os.path.exists(path):
         return None
     try:
@@ -576,12 +579,12 @@ def load_obj_native(obj_file: str, entry: str = "fovpt_model_load_obj") -> Model
     caller gets from `loadOBJ` in include/Model.h.  Each mesh also carries `.normal` ((N,3) float32 or None)."""
     import ctypes as C
     from . import abi, lib
-    L = lib.load()
+    L = lib.load_loader()
     h = C.c_void_p()
-    lib.check(None, getattr(L, entry)(os.fsencode(obj_file), C.byref(h)))
+    lib.check(None, getattr(L, entry)(os.fsencode(obj_file), C.byref(h)), L)
     try:
         nm, nt = C.c_int(0), C.c_int(0)
-        lib.check(None, L.fovpt_model_counts(h, C.byref(nm), C.byref(nt)))
+        lib.check(None, L.fovpt_model_counts(h, C.byref(nm), C.byref(nt)), L)
         model = Model()
 
         def arr(ptr, n, cols, dtype):
@@ -590,7 +593,7 @@ def load_obj_native(obj_file: str, entry: str = "fovpt_model_load_obj") -> Model
             return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint32)), (n * cols,)).view(dtype).reshape(n, cols).copy()
         for k in range(nm.value):
             d = abi.ModelMesh()
-            lib.check(None, L.fovpt_model_get_mesh(h, k, C.byref(d)))
+            lib.check(None, L.fovpt_model_get_mesh(h, k, C.byref(d)), L)
             mat = Material()
             C.memmove(C.byref(mat), C.byref(d.material), C.sizeof(Material))
             mesh = TriangleMesh(arr(d.vertex, d.num_vertices, 3, np.float32), arr(d.index, d.num_triangles, 3, np.uint32), mat,
@@ -599,7 +602,7 @@ def load_obj_native(obj_file: str, entry: str = "fovpt_model_load_obj") -> Model
             model.meshes.append(mesh)
         for k in range(nt.value):
             px, w, hh = C.c_void_p(), C.c_int(0), C.c_int(0)
-            lib.check(None, L.fovpt_model_get_texture(h, k, C.byref(px), C.byref(w), C.byref(hh)))
+            lib.check(None, L.fovpt_model_get_texture(h, k, C.byref(px), C.byref(w), C.byref(hh)), L)
             model.textures.append(np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_uint32)), (hh.value, w.value)).copy())
         return model
     finally:
@@ -747,9 +750,9 @@ def load_probe_texels_native(path: str) -> np.ndarray:
     """The same texels through the library (fovpt_image_load_float4, csrc/model_loader.cpp): .hdr, .png, binary .ppm."""
     import ctypes as C
     from . import lib
-    L = lib.load()
+    L = lib.load_loader()
     w, h, px = C.c_int(0), C.c_int(0), C.c_void_p()
-    lib.check(None, L.fovpt_image_load_float4(os.fsencode(path), C.byref(w), C.byref(h), C.byref(px)))
+    lib.check(None, L.fovpt_image_load_float4(os.fsencode(path), C.byref(w), C.byref(h), C.byref(px)), L)
     try:
         return np.ctypeslib.as_array(C.cast(px, C.POINTER(C.c_float)), (h.value, w.value, 4)).copy()
     finally:

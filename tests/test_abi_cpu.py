@@ -33,6 +33,34 @@ def test_library_exports_every_declared_symbol(so):
     assert sorted(lib.EXPORTS) == names
 
 
+def test_host_only_loader_library(so, tmp_path):
+    """csrc/libfovpt_loader.so: the scene / image ingestion of the C ABI as a host-only shared object -- it exports
+    every fovpt_model_* / fovpt_image_* entry point of include/fovpt.h, depends on no HIP / HSA library, and a fresh interpreter
+    that only reads files through the python loaders never maps libfovpt.so or the HIP runtime."""
+    path = lib.LOADER_SO_PATH
+    assert os.path.exists(path), "make -C csrc builds libfovpt_loader.so beside libfovpt.so"
+    L = C.CDLL(path)
+    wanted = [n for n in _declared_functions() if n.startswith("fovpt_model_") or n.startswith("fovpt_image_")]
+    assert len(wanted) >= 10 and sorted(wanted + ["fovpt_last_error"]) == sorted(lib.LOADER_EXPORTS)
+    for n in wanted:
+        assert hasattr(L, n), n
+    deps = subprocess.run(["ldd", path], capture_output=True, text=True).stdout
+    assert "hip" not in deps.lower() and "hsa" not in deps.lower() and "rocm" not in deps.lower(), deps
+    (tmp_path / "t.ppm").write_bytes(b"P6\n2 1\n255\n" + bytes([255, 0, 0, 0, 0, 255]))
+    (tmp_path / "m.mtl").write_text("newmtl m\nKd 1 1 1\nmap_Kd t.ppm\n")
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\nv 0 0 0\nv 1 0 0\nv 0 1 0\nvt 0 0\nusemtl m\nf 1/1 2/1 3/1\n")
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from fovpathtracing_optixcodelatest_amd import loaders\n"
+            "m = loaders.load_obj_native(%r)\n"
+            "assert len(m.meshes) == 1 and len(m.textures) == 1 and m.textures[0].shape == (1, 2)\n"
+            "maps = open('/proc/self/maps').read()\n"
+            "assert 'libfovpt_loader.so' in maps and 'libfovpt.so' not in maps and 'libamdhip64' not in maps, maps[-2000:]\n"
+            % (ROOT, str(tmp_path / "m.obj")))
+    env = {k: v for k, v in os.environ.items() if k != "FOVPT_SO"}
+    res = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+
+
 def test_struct_layouts_match_reference_abi():
     assert C.sizeof(abi.Material) == 104          # Material.h:48-69
     assert C.sizeof(abi.Probe) == 64              # Probe.cuh:6-21

@@ -242,6 +242,28 @@ def test_cpp_host_gathers_over_rccl(tmp_path):
     assert np.array_equal(px[0], px[1]), res.stdout
 
 
+def test_python_host_gathers_over_the_library_transport():
+    """`bench.py --gather lib` in small: the library's own RCCL transport driven from python -- fovpt_comm_get_unique_id,
+    fovpt_comm_init with a communicator of one rank, fovpt_gather_frame IN PLACE (the root gathers into the frame it rendered
+    into) three frames back to back -- leaves the frame what the renderer alone produces."""
+    size = (160, 96)
+    cfg = cfg_foveated(12, 40, (1, 2, 4))
+    model, probe = scenes.atrium(6000), scenes.ambient_probe(64, 32, 2.5)
+    r = make_gpu(model, probe, scenes.ATRIUM_CAMERA, size, cfg)
+    r.render()
+    want = r.downloadPixels()
+    r.comm_init(renderer.SampleRenderer.comm_unique_id(), 0, 1)
+    fb = r.launchParams.frame.frame_buffer
+    for _ in range(3):
+        r.launchParams.frame.subframe_index = 0
+        r.render_async()
+        r.gather_frame(0, fb, fb)
+    got = r.downloadPixels()
+    r.comm_destroy()
+    r.close()
+    assert (want != 0).sum() > 0.9 * want.size and np.array_equal(got, want)
+
+
 @pytest.mark.parametrize("budget", ["0.3", "1.0"])
 def test_spatial_splits_do_not_change_the_frame(oracle, budget, monkeypatch):
     """Spatial splits in the hierarchy build (FOVPT_SPLIT: long triangles enter the build as several references, each a leaf
@@ -277,6 +299,46 @@ def test_spatial_splits_do_not_change_the_frame(oracle, budget, monkeypatch):
     S, F = make_oracle(oracle, model, probe, scenes.ATRIUM_CAMERA, size)
     oracle.render(S, F, cfg)
     assert np.array_equal(got_f, F.frame)
+
+
+def test_reinsertion_does_not_change_the_frame(oracle, monkeypatch):
+    """Reinsertion rounds on the PLOC tree (bvh_build.hip k_reinsert_*: subtrees are taken out and put back where the tree's SAH cost
+    falls most -- part of what replaces optixAccelBuild, SimplePathtracer.cpp:677-735) change the hierarchy and nothing else:
+    closest hit (minimum (t, primitive id)), the occlusion predicate, the frame and the ray counts of a scene of facade modules
+    and large foliage cards are the same without it (FOVPT_REINSERT=0), with the default rounds and with 40, and equal to the
+    oracle's; the hierarchy itself is not the same (fewer or more wide nodes)."""
+    size = (192, 108)
+    model = scenes.street(24000, material="app")
+    cfg = cfg_foveated(14, 46, (1, 2, 4))
+    probe = scenes.sky_probe(64, 32, seed=5)
+    rng = np.random.default_rng(77)
+    v = np.concatenate([m.vertex for m in model.meshes])
+    lo, hi = v.min(0), v.max(0)
+    o = (lo + (hi - lo) * rng.random((4096, 3))).astype(np.float32)
+    d = rng.normal(size=(4096, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    got = {}
+    for rounds in ("0", None, "40"):
+        if rounds is None:
+            monkeypatch.delenv("FOVPT_REINSERT", raising=False)
+        else:
+            monkeypatch.setenv("FOVPT_REINSERT", rounds)
+        r = make_gpu(model, probe, scenes.STREET_CAMERA, size, cfg)
+        r.render()
+        got[rounds] = (r.downloadAccum(), r.downloadPixels(), r.stats(), r.debug_trace(o, d))
+        r.close()
+    a0, f0, st0, p0 = got["0"]
+    assert st0.radiance_rays > 0 and st0.shadow_rays > 0
+    for rounds in (None, "40"):
+        a1, f1, st1, p1 = got[rounds]
+        assert np.array_equal(a1.view(np.uint32), a0.view(np.uint32)) and np.array_equal(f1, f0), rounds
+        assert (st1.paths, st1.radiance_rays, st1.shadow_rays) == (st0.paths, st0.radiance_rays, st0.shadow_rays), rounds
+        assert np.array_equal(p0[0], p1[0]) and np.array_equal(p0[1].view(np.uint32), p1[1].view(np.uint32)) and np.array_equal(p0[2], p1[2]), rounds
+        assert st1.num_triangles == st0.num_triangles
+    assert got[None][2].num_bvh_nodes != st0.num_bvh_nodes or got["40"][2].num_bvh_nodes != st0.num_bvh_nodes      # the tree did change
+    S, F = make_oracle(oracle, model, probe, scenes.STREET_CAMERA, size)
+    oracle.render(S, F, cfg)
+    assert np.array_equal(f0, F.frame)
 
 
 def _write_textured_obj(tmp_path):
