@@ -9,12 +9,15 @@ Step   : one SampleRenderer::render() frame (three foveation passes) of workload
          (PT_sv5_/main.cpp:402-407).  All inputs are synthetic and resident in HBM before the timed region.
 N > 1  : ONE frame is sharded by interleaved launch-index tiles over the ranks (strong scaling); each rank renders its
          tiles, packs the pixels it owns (HIP) and RCCL gathers the packed buffers onto rank 0 over xGMI, which scatters
-         them into the frame (fovpt_gather_*; --gather reduce = the older full-frame sum-reduce).
+         them into the frame (fovpt_gather_*; --gather reduce = the older full-frame sum-reduce; --gather lib = the library's OWN RCCL
+         transport, fovpt_comm_init / fovpt_gather_frame, what a C++ host uses).
 
-Prints ONE JSON line on rank 0 (contract in the task description) carrying
-  roofline      dominant kernel k_traverse: algorithmic bytes / HIP-event time (the contract's figure), `bound` = what the
-                evidence says binds (the latency of the node step's dependent chain: neither HBM nor the vector ALU, which issues
-                ~40-50 % of its rate), `traffic` and `valu` measured IN THIS RUN
+Prints ONE JSON line on rank 0 (contract in the task description) carrying `value` (frames back to back, two in flight) and
+`value_sync_per_frame` (one frame at a time, render() + synchronise: SURVEY 8(d)'s own definition of the metric), and
+  roofline      dominant kernel k_traverse: algorithmic bytes / HIP-event time AS THE TIMED REGION RUNS (the contract's figure), `bound` =
+                what the evidence says binds (the CUs' L1 address / data path, with the node step's dependent chain on top: neither HBM
+                nor the vector ALU), flat keys `l1_frac` (texture-addresser busy time of a frame's loads / frame interval), `lane_use`,
+                `hbm_frac_measured`; `traffic`, `valu` and `l1_path` measured IN THIS RUN
                 by rocprofv3 --pmc child passes of this same script (or, failing that, imported from profiles/ and said so),
                 per-kernel times both overlapped (as the frame runs) and serialised (every kernel alone)
   cpu_baseline  the CPU oracle timed on the host cores on the same frame (N = 1)

@@ -843,7 +843,7 @@ __device__ inline void node_step(const SceneView& sc, const RayT& r, const QuadL
     // Every lane stores its child: the H hits land on rows top .. top+H-1 (the one to visit next
     // last), the misses on the free rows above them -- no branch, no select on the address.
     int row;                                    // in bytes, relative to top
-    if (ANY_HIT) {
+    if (ANY_HIT && !FOVPT_V_ANYHIT_SORT) {
         // storage order (distance order was measured slower)
         row = ((__builtin_popcount(m4 & q.from_me) - 1) << ROWSHIFT) + (h ? 0 : q.miss_rows);
     } else {
@@ -961,6 +961,21 @@ __device__ inline void store_shadow(const PathState& ps, const ShadowQueue& sq, 
 // A node step sits on the wave's dependent chain (load -> test -> rank -> stack -> pop -> load), so it is kept short: the hit mask of the quad comes out of the wave
 // ballot (one shift), every lane stores its child at a row derived from its rank and the next node is
 // simply popped -- descending and backtracking are the same code, no cross-lane selects.
+// na live lanes of the wave, nn of them at a node: does the node phase end here?  (FOVPT_VOTE_C = 64: never -- the phases of rounds 1-3)
+#ifndef FOVPT_VOTE_A
+#define FOVPT_VOTE_A 2
+#endif
+#ifndef FOVPT_VOTE_B
+#define FOVPT_VOTE_B 1
+#endif
+#ifndef FOVPT_VOTE_C
+#define FOVPT_VOTE_C 1
+#endif
+__device__ inline bool vote_leaf(uint32_t na, uint32_t nn)
+{
+    return (na - nn) * (uint32_t)FOVPT_VOTE_A >= nn * (uint32_t)FOVPT_VOTE_B + 4u * (uint32_t)FOVPT_VOTE_C;
+}
+
 __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __restrict__ stack /* [e * QUADS_PER_BLOCK] */, const QuadLane& q,
                               QuadTrav& T, unsigned long long* diag CYC_P)
 {
@@ -968,28 +983,39 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
 #if FOVPT_V_CYCLES
     if (C.on) s_cyc_last = cyc_stamp();
 #endif
+    // The wave VOTES when its node phase ends (round 4).  Rounds 1-3 ran node steps until EVERY ray of the wave had reached a leaf (or
+    // was through): a ray at a leaf waited for the longest run of node steps among the other fifteen, and only 8.3 (atrium) / 5.8
+    // (street) of the 16 rays took part in an average node step.  Now the phase ends as soon as the rays waiting at a leaf
+    // outnumber those still stepping (vote_leaf: waiting x A >= stepping x B + C quads): a leaf step then serves the waiting rays,
+    // the stepping ones sit it out and go on afterwards.  Leaf steps get emptier (9.3 -> 5.2 rays of 16, and 77 % more of them),
+    // node steps fuller (8.3 -> 10.6, 22 % fewer): in node-step units (a leaf step costs 1.4) a wave's passes fall by 7 % on the
+    // atrium and by 27 % on the street.  The vote rides on what the loop computes anyway -- the lanes that go on are the loop's
+    // own exit mask, one s_bcnt1 and six scalar instructions -- after a first form with a ballot per state and a branch per pass
+    // cost 12-15 % per pass and lost on the atrium (EXPERIMENTS.md).  Order of steps never changes a result.
 #if FOVPT_V_STEPSTAT
     // (no arrays with a run-time index here: a diagnostic build whose traversal kernel used scratch memory faulted with
     // HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on the closest-hit launch; the product kernels use none)
-    uint32_t nn = 0, nl = 0;
-    T.tr_lo = T.tr_hi = 0ull; T.n0 = 0u;
-    for (;;) {
-        uint32_t ph = 0;
-        while (T.cur >= 0) { STEPSTAT(diag); node_step<false>(sc, r, q, T CYC_A); nn++; ph++; }
-        { const unsigned long long v = (unsigned long long)min(ph, 255u) << ((nl & 7u) * 8u); if (nl < 8u) T.tr_lo |= v; else if (nl < 15u) T.tr_hi |= v; }
-        if (T.cur == TRAV_DONE) break;
-        STEPSTAT(diag + 2);
-        leaf_step<false>(sc, r, q, T CYC_A); nl++;
-    }
-    T.steps = min(nn, 4095u) | (min(nl, 255u) << 12) | (min(T.n0, 63u) << 20);      // (bits 26-31: dropped pops of round 4's pruning experiment, tools/stepcount.py)
-    T.tr_hi |= (unsigned long long)min(T.n0, 255u) << 56;
+    uint32_t my_nodes = 0u, my_leaves = 0u;          // this ray's own steps (tools/stepcount.py, raystat.py); the per-phase trace is not kept any more
+    T.n0 = 0u; T.tr_lo = T.tr_hi = 0ull;
+#define RAYSTAT(x) (x)++
 #else
-    for (;;) {
-        while (T.cur >= 0) node_step<false>(sc, r, q, T CYC_A);
-        if (T.cur == TRAV_DONE) return;
-        leaf_step<false>(sc, r, q, T CYC_A);
-    }
+#define RAYSTAT(x)
 #endif
+    while (T.cur != TRAV_DONE) {                                                                         // (rays that are through leave)
+        const uint32_t na = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));            // live lanes of the wave
+        while (T.cur >= 0) {
+            STEPSTAT(diag);
+            node_step<false>(sc, r, q, T CYC_A);
+            RAYSTAT(my_nodes);
+            const uint32_t nn = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(T.cur >= 0));   // of the lanes that stepped: who goes on
+            if (vote_leaf(na, nn)) break;                                                                  // (wave-uniform)
+        }
+        if (T.cur < 0 && T.cur != TRAV_DONE) { STEPSTAT(diag + 2); leaf_step<false>(sc, r, q, T CYC_A); RAYSTAT(my_leaves); }
+    }
+#if FOVPT_V_STEPSTAT
+    T.steps = min(my_nodes, 4095u) | (min(my_leaves, 255u) << 12) | (min(T.n0, 63u) << 20);
+#endif
+#undef RAYSTAT
 }
 
 // Any-hit traversal over a POOL of shadow rays [first, end) owned by one wave: a quad that has finished
@@ -1037,8 +1063,20 @@ __device__ inline void traverse_shadow_pool(const SceneView& sc, const PathState
 #endif
             if (n_idle == 16u && __builtin_amdgcn_ballot_w64(T.cur != TRAV_DONE) == 0ull) return;      // pool exhausted, all results stored
         }
+#if FOVPT_V_VOTE_ANYHIT
+        // the same vote as for closest-hit rays (traverse_quad); the live lanes are the quads that hold a ray
+        const uint32_t na = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(T.cur != TRAV_DONE));
+        while (T.cur >= 0) {
+            STEPSTAT(diag);
+            node_step<true>(sc, r, q, T CYC_A);
+            const uint32_t nn = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(T.cur >= 0));
+            if (vote_leaf(na, nn)) break;
+        }
+        if (T.cur < 0 && T.cur != TRAV_DONE) {
+#else
         while (T.cur >= 0) { STEPSTAT(diag); node_step<true>(sc, r, q, T CYC_A); }
         if (T.cur != TRAV_DONE) {
+#endif
             STEPSTAT(diag + 2);
             if (leaf_step<true>(sc, r, q, T CYC_A)) { occluded = true; T.cur = TRAV_DONE; }
         }
