@@ -975,6 +975,20 @@ __device__ inline bool vote_leaf(uint32_t na, uint32_t nn)
 {
     return (na - nn) * (uint32_t)FOVPT_VOTE_A >= nn * (uint32_t)FOVPT_VOTE_B + 4u * (uint32_t)FOVPT_VOTE_C;
 }
+// (occlusion rays: the same rule with its own constants, for A/B)
+#ifndef FOVPT_VOTE_AH_A
+#define FOVPT_VOTE_AH_A FOVPT_VOTE_A
+#endif
+#ifndef FOVPT_VOTE_AH_B
+#define FOVPT_VOTE_AH_B FOVPT_VOTE_B
+#endif
+#ifndef FOVPT_VOTE_AH_C
+#define FOVPT_VOTE_AH_C FOVPT_VOTE_C
+#endif
+__device__ inline bool vote_leaf_anyhit(uint32_t na, uint32_t nn)
+{
+    return (na - nn) * (uint32_t)FOVPT_VOTE_AH_A >= nn * (uint32_t)FOVPT_VOTE_AH_B + 4u * (uint32_t)FOVPT_VOTE_AH_C;
+}
 
 __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __restrict__ stack /* [e * QUADS_PER_BLOCK] */, const QuadLane& q,
                               QuadTrav& T, unsigned long long* diag CYC_P)
@@ -1070,7 +1084,7 @@ __device__ inline void traverse_shadow_pool(const SceneView& sc, const PathState
             STEPSTAT(diag);
             node_step<true>(sc, r, q, T CYC_A);
             const uint32_t nn = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(T.cur >= 0));
-            if (vote_leaf(na, nn)) break;
+            if (vote_leaf_anyhit(na, nn)) break;
         }
         if (T.cur < 0 && T.cur != TRAV_DONE) {
 #else
