@@ -268,6 +268,7 @@ SceneView scene_view(const fovpt_ctx* c)
     sc.meshes = (const MeshDev*)c->meshes.p; sc.textures = (const TexDev*)c->textures.p;
     sc.num_tris = c->num_tris; sc.any_catcher = c->any_catcher;
     sc.tri_off = (uint32_t)((const char*)c->tris - (const char*)c->nodes);
+    sc.num_nodes = c->stats.num_bvh_nodes;
     return sc;
 }
 

@@ -98,6 +98,7 @@ struct SceneView {
     uint32_t num_tris;
     uint32_t any_catcher;
     uint32_t tri_off;             // (const char*)tris - (const char*)nodes: one base register reaches both
+    uint32_t num_nodes;           // wide nodes of the hierarchy
 };
 
 

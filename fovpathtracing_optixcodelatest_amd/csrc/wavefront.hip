@@ -815,8 +815,22 @@ __device__ inline void cyc_hist(uint32_t* h, uint32_t bin) { if (FOVPT_V_CYCLES 
 #define CYC_A
 #endif
 
+// The root and its children -- the first FOVPT_TOPN nodes of the breadth-first array, 640 bytes -- live in LDS beside a closest-hit
+// wave's stack (4352 + 640 bytes: still eight waves per SIMD), and the first two steps of every ray of a round read them from
+// there instead of through the CU's address path: all sixteen rays of a round start at the root together and most go on to one of
+// its children, so the two steps are peeled in front of the loop (no per-step choice between the two memories).  Round 4,
+// closest-hit launches -1.2 %, frames -1 % (atrium 0.676 -> 0.669, street 1.456 -> 1.439).  Occlusion rays
+// start one by one (pool refills): for them a peeled step would be a pass of its own, and they keep the global path.
+#ifndef FOVPT_V_TOPLDS
+#define FOVPT_V_TOPLDS 1
+#endif
+#define FOVPT_TOPN 5
+#if FOVPT_V_TOPLDS
+__shared__ float4 s_top[FOVPT_TOPN * 8];
+#endif
+
 // wide internal node: lane j owns child j
-template <bool ANY_HIT>
+template <bool ANY_HIT, bool TOP = false>
 __device__ inline void node_step(const SceneView& sc, const RayT& r, const QuadLane& q, QuadTrav& T CYC_P)
 {
 #if FOVPT_V_CYCLES
@@ -828,6 +842,13 @@ __device__ inline void node_step(const SceneView& sc, const RayT& r, const QuadL
 #if FOVPT_V_CYCLES
     float4 a = np[0], b = np[1];
     if (C.on) c1 = cyc_stamp(a.x, b.z);
+#elif FOVPT_V_TOPLDS
+    float4 a, b;
+    if (TOP) {
+        typedef __attribute__((address_space(3))) float LdsFloat;
+        const LdsFloat* lp = (const LdsFloat*)((const LdsChar*)(LdsFloat*)(float*)s_top + (((uint32_t)T.cur << 7) | q.j32));
+        a = make_float4(lp[0], lp[1], lp[2], lp[3]); b = make_float4(lp[4], lp[5], lp[6], lp[7]);
+    } else { a = np[0]; b = np[1]; }
 #else
     const float4 a = np[0], b = np[1];
 #endif
@@ -1015,6 +1036,15 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
 #else
 #define RAYSTAT(x)
 #endif
+#if FOVPT_V_TOPLDS
+    // every ray of a round starts at the root, and most go on to one of its children: those two steps out of LDS
+    if (sc.num_nodes >= FOVPT_TOPN) {
+        STEPSTAT(diag);
+        node_step<false, true>(sc, r, q, T CYC_A);
+        RAYSTAT(my_nodes);
+        if (T.cur >= 0 && T.cur < FOVPT_TOPN) { STEPSTAT(diag); node_step<false, true>(sc, r, q, T CYC_A); RAYSTAT(my_nodes); }
+    }
+#endif
     while (T.cur != TRAV_DONE) {                                                                         // (rays that are through leave)
         const uint32_t na = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(true));            // live lanes of the wave
         while (T.cur >= 0) {
@@ -1124,6 +1154,12 @@ __global__ __launch_bounds__(FOVPT_TBLOCK, FOVPT_V_WAVES) void k_traverse(SceneV
     QuadLane q;
     q.init();
     int* stack = s_stack + (threadIdx.x >> 2);
+#if FOVPT_V_TOPLDS
+    if (MODE != 1 && sc.num_nodes >= FOVPT_TOPN) {
+        for (uint32_t k = threadIdx.x; k < FOVPT_TOPN * 8u; k += FOVPT_TBLOCK) s_top[k] = ((const float4*)sc.nodes)[k];
+        __syncthreads();
+    }
+#endif
 #if FOVPT_V_CYCLES
     if (threadIdx.x < 192) s_cyc_hist[threadIdx.x] = 0u;
     if (threadIdx.x == 0) s_cyc_last = 0u;
