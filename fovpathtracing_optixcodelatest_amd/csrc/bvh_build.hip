@@ -403,6 +403,13 @@ template <typename F> __device__ inline void reinsert_touch(const TreeView& T, i
     const int s = T.left[p] == c ? T.right[p] : T.left[p];
     f(T.slot(c)); f(T.slot(p)); f(T.slot(s)); f(T.slot(q)); f(T.slot(mv.out)); f(T.slot(T.parent(mv.out)));
 }
+// one atomic per wave for a counter that many lanes bump (a returning or non-returning atomic on ONE word drains at ~88 per
+// microsecond on this chip: 300 k candidates one by one were 3.5 ms of every round)
+__device__ inline void wave_count(uint32_t* counter)
+{
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
+    if ((threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) atomicAdd(counter, (uint32_t)__builtin_popcountll(m));
+}
 __device__ inline unsigned long long move_key(const Move& mv, uint32_t x) { return ((unsigned long long)__float_as_uint(mv.gain) << 32) | (unsigned long long)x; }
 __global__ void k_reinsert_lock(TreeView T, const Move* __restrict__ moves, unsigned long long* __restrict__ lock, uint32_t* __restrict__ counts)
 {
@@ -413,7 +420,7 @@ __global__ void k_reinsert_lock(TreeView T, const Move* __restrict__ moves, unsi
     const int c = x < (uint32_t)(T.n - 1) ? (int)x : ~(int)(x - (uint32_t)(T.n - 1));
     const unsigned long long key = move_key(mv, x);
     reinsert_touch(T, c, mv, [&](uint32_t i) { atomicMax(&lock[i], key); });
-    atomicAdd(&counts[2], 1u);                         // candidates (diagnostics)
+    wave_count(&counts[2]);                            // candidates (diagnostics)
 }
 // first check: the move owns its six nodes.  A survivor marks the node it moves.
 __global__ void k_reinsert_check(TreeView T, Move* __restrict__ moves, const unsigned long long* __restrict__ lock, unsigned char* __restrict__ moving)
@@ -445,7 +452,7 @@ __global__ void k_reinsert_check2(TreeView T, const Move* __restrict__ moves, co
     for (int a = T.parent(mv.out); a >= 0 && a != mv.pivot; a = T.parent_int[a])
         if (moving[T.slot(a)] && lock[T.slot(a)] > key) { y = true; break; }      // (a survivor owns the stamp of the node it moves)
     yield[x] = y ? 1 : 0;
-    if (!y) atomicAdd(&counts[0], 1u);
+    if (!y) wave_count(&counts[0]);
 }
 __device__ inline void set_parent(const TreeView& T, int c, int p) { if (c < 0) T.parent_leaf[~c] = p; else T.parent_int[c] = p; }
 __global__ void k_reinsert_apply(TreeView T, const Move* __restrict__ moves, const unsigned char* __restrict__ yield)
@@ -469,30 +476,45 @@ __global__ void k_reinsert_apply(TreeView T, const Move* __restrict__ moves, con
     if (T.left[p] == c) T.right[p] = y; else T.left[p] = y;
     set_parent(T, y, p);
 }
-// boxes, subtree sizes and child sides of the whole tree, bottom-up (the second thread to arrive at a node does it, as k_refit)
-__global__ void k_tree_refit(TreeView T, uint32_t* __restrict__ size_int, unsigned char* __restrict__ side_int, unsigned char* __restrict__ side_leaf,
-                             uint32_t* __restrict__ arrive, float* __restrict__ cost)
+// Bottom-up passes over an ARBITRARY binary tree (the reinserted one has no rounds and no ranges to go by), level-synchronous:
+// a sweep is one thread per internal node, and a node is computed in the first sweep that finds both its children finished by
+// an EARLIER sweep (`done` holds the sweep that finished a node, + 1; a kernel boundary lies between writer and reader, so no
+// fence is needed).  The climbing form of rounds 1-3 (k_refit / k_dp_collapse: the second thread to arrive at a node computes it,
+// `__threadfence` + a returning atomic per level) costs 24 ms per pass over 3.8 M leaves on this chip -- 292 of the 414 ms of a
+// build with twelve reinsertion rounds -- because an agent-scope fence writes back and invalidates an XCD's L2; a sweep reads one
+// flag per finished node and costs ~20 us, and a tree of 3.8 M leaves is 60-90 sweeps high.
+//   MODE 0: boxes, subtree sizes, child sides, and the tree's cost (sum of the internal nodes' areas)
+//   MODE 1: the collapse's dynamic programme (dp_node)
+struct DpCost;
+__device__ inline void dp_node(int node, const Box* __restrict__ boxes, const uint32_t* __restrict__ vals, const int* __restrict__ left,
+                               const int* __restrict__ right, const uint32_t* __restrict__ size_int, const Box* __restrict__ ibox, DpCost* dp);
+template <int MODE>
+__global__ void k_sweep_up(TreeView T, uint32_t sweep, unsigned short* __restrict__ done, uint32_t* __restrict__ size_int,
+                           unsigned char* __restrict__ side_int, unsigned char* __restrict__ side_leaf, float* __restrict__ cost, DpCost* __restrict__ dp)
 {
-    const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
-    if (leaf >= T.n) return;
-    int node = T.parent_leaf[leaf];
-    float local = 0.f;
-    while (node >= 0) {
-        __threadfence();
-        if (atomicAdd(&arrive[node], 1u) == 0u) break;
-        __threadfence();
+    const int node = blockIdx.x * blockDim.x + threadIdx.x;
+    float area = 0.f;
+    if (node < T.n - 1 && done[node] == 0) {
         const int lc = T.left[node], rc = T.right[node];
-        const Box a = T.box(lc), b = T.box(rc);
-        Box u;
-        for (int k = 0; k < 3; k++) { u.lo[k] = fminf(a.lo[k], b.lo[k]); u.hi[k] = fmaxf(a.hi[k], b.hi[k]); }
-        T.ibox[node] = u;
-        size_int[node] = (lc < 0 ? 1u : size_int[lc]) + (rc < 0 ? 1u : size_int[rc]);
-        if (lc < 0) side_leaf[~lc] = 0; else side_int[lc] = 0;
-        if (rc < 0) side_leaf[~rc] = 1; else side_int[rc] = 1;
-        local += box_area(u);
-        node = T.parent_int[node];
+        const uint32_t dl = lc < 0 ? 1u : done[lc], dr = rc < 0 ? 1u : done[rc];
+        if (dl != 0u && dl <= sweep && dr != 0u && dr <= sweep) {           // both finished BEFORE this sweep (leaves always are)
+            if (MODE == 0) {
+                const Box a = T.box(lc), b = T.box(rc);
+                Box u;
+                for (int k = 0; k < 3; k++) { u.lo[k] = fminf(a.lo[k], b.lo[k]); u.hi[k] = fmaxf(a.hi[k], b.hi[k]); }
+                T.ibox[node] = u;
+                size_int[node] = (lc < 0 ? 1u : size_int[lc]) + (rc < 0 ? 1u : size_int[rc]);
+                if (lc < 0) side_leaf[~lc] = 0; else side_int[lc] = 0;
+                if (rc < 0) side_leaf[~rc] = 1; else side_int[rc] = 1;
+                area = box_area(u);
+            } else dp_node(node, T.boxes, T.vals, T.left, T.right, size_int, T.ibox, dp);
+            done[node] = (unsigned short)(sweep + 1u);
+        }
     }
-    if (cost && local != 0.f) atomicAdd(cost, local);
+    if (MODE == 0 && cost) {                                                // one atomic per wave
+        for (int off = 32; off > 0; off >>= 1) area += __shfl_xor(area, off);
+        if ((threadIdx.x & 63) == 0 && area != 0.f) atomicAdd(cost, area);
+    }
 }
 
 __device__ inline float box_area(const Box& b)
@@ -917,6 +939,27 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
     uint32_t h_counters[2] = {1, 0};
     hipError_t rc = hipSuccess;
     err[0] = 0;
+    // bottom-up sweeps over the binary tree until the root is finished (k_sweep_up); false + err on failure
+    auto sweep_up = [&](int mode, const TreeView& T, float* cost) -> bool {
+        const uint32_t nint = (uint32_t)T.n - 1u, g = (nint + 255u) / 256u;
+        if (!re_arrive && hipMalloc(&re_arrive, 2ull * nint) != hipSuccess) { snprintf(err, errlen, "hipMalloc failed (sweep flags)"); return false; }
+        if (hipMemsetAsync(re_arrive, 0, 2ull * nint, st) != hipSuccess) { snprintf(err, errlen, "hipMemsetAsync failed (sweep flags)"); return false; }
+        unsigned short* done = (unsigned short*)re_arrive;
+        for (uint32_t sweep = 0; sweep < 65000u;) {
+            for (int k = 0; k < 16; k++, sweep++) {
+                if (mode == 0) hipLaunchKernelGGL(k_sweep_up<0>, dim3(g), dim3(256), 0, st, T, sweep, done, size_int, side_int, side_leaf, cost, (DpCost*)nullptr);
+                else hipLaunchKernelGGL(k_sweep_up<1>, dim3(g), dim3(256), 0, st, T, sweep, done, size_int, side_int, side_leaf, (float*)nullptr, dp);
+            }
+            unsigned short root_done = 0;
+            if (hipMemcpyAsync(&root_done, done + (nint - 1u), 2, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+                snprintf(err, errlen, "bottom-up sweep failed: %s", hipGetErrorString(hipGetLastError()));
+                return false;
+            }
+            if (root_done) return true;
+        }
+        snprintf(err, errlen, "bottom-up sweeps did not reach the root");
+        return false;
+    };
     for (int a = 0; a < 3; a++) { h_bounds[a] = 0xffffffffu; h_bounds[3 + a] = 0u; }
     HC(hipMalloc(&bounds, 6 * 4));
     if (split_budget > 0.f && n_prims > FOVPT_LEAF_MAX) {
@@ -1037,13 +1080,13 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
                 const uint32_t nall = 2 * n - 1, gall2 = (nall + B - 1) / B;
                 HC(hipMalloc(&re_moves, sizeof(Move) * (size_t)nall));
                 HC(hipMalloc(&re_lock, 8ull * nall));
-                HC(hipMalloc(&re_arrive, 4ull * ni));
+                HC(hipMalloc(&re_arrive, 2ull * ni));                     // (the sweep that finished each node, + 1)
                 HC(hipMalloc(&re_scalars, 16));
                 HC(hipMalloc(&re_flags, 2ull * nall));
                 // the cost of the tree as PLOC left it (what the first round's gain is measured against)
                 float cost_prev = 0.f;
-                HC(hipMemsetAsync(re_arrive, 0, 4ull * ni, st)); HC(hipMemsetAsync(re_scalars, 0, 16, st));
-                hipLaunchKernelGGL(k_tree_refit, dim3(gn), dim3(B), 0, st, T, size_int, side_int, side_leaf, re_arrive, (float*)(re_scalars + 1));
+                HC(hipMemsetAsync(re_scalars, 0, 16, st));
+                if (!sweep_up(0, T, (float*)(re_scalars + 1))) goto fail;
                 HC(hipMemcpyAsync(&cost_prev, re_scalars + 1, 4, hipMemcpyDeviceToHost, st));
                 HC(hipStreamSynchronize(st));
                 if (verbose) fprintf(stderr, "[fovpt bvh] PLOC tree: sum of internal areas %.6g\n", (double)cost_prev);
@@ -1058,8 +1101,7 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
                     hipLaunchKernelGGL(k_reinsert_check, dim3(gall2), dim3(B), 0, st, T, re_moves, re_lock, re_flags);
                     hipLaunchKernelGGL(k_reinsert_check2, dim3(gall2), dim3(B), 0, st, T, re_moves, re_lock, re_flags, re_flags + nall, re_scalars);
                     hipLaunchKernelGGL(k_reinsert_apply, dim3(gall2), dim3(B), 0, st, T, re_moves, re_flags + nall);
-                    HC(hipMemsetAsync(re_arrive, 0, 4ull * ni, st));
-                    hipLaunchKernelGGL(k_tree_refit, dim3(gn), dim3(B), 0, st, T, size_int, side_int, side_leaf, re_arrive, (float*)(re_scalars + 1));
+                    if (!sweep_up(0, T, (float*)(re_scalars + 1))) goto fail;
                     uint32_t candidates = 0;
                     HC(hipMemcpyAsync(&applied, re_scalars, 4, hipMemcpyDeviceToHost, st));
                     HC(hipMemcpyAsync(&cost, re_scalars + 1, 4, hipMemcpyDeviceToHost, st));
@@ -1087,6 +1129,12 @@ hipError_t fovpt_build_lbvh(hipStream_t st, const float* flat, const uint32_t* m
                                        left, right, size_int, ibox, dp);
                 first = end;
             }
+        } else if (use_ploc) {
+            // a reinserted tree: the same programme in bottom-up sweeps (k_sweep_up)
+            TreeView T;
+            T.n = (int)n; T.left = left; T.right = right; T.parent_int = parent_int; T.parent_leaf = parent_leaf;
+            T.ibox = ibox; T.boxes = boxes; T.vals = vals_s;
+            if (!sweep_up(1, T, nullptr)) goto fail;
         } else {
             HC(hipMalloc(&dp_arrive, 4ull * ni));
             HC(hipMemsetAsync(dp_arrive, 0, 4ull * ni, st));
