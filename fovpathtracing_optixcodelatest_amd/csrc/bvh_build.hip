@@ -333,6 +333,9 @@ struct Move { int out; int pivot; float gain; };
 #ifndef FOVPT_REINSERT_DEFAULT
 #define FOVPT_REINSERT_DEFAULT 12          // at most this many rounds; a round that lowers the cost by less than FOVPT_REINSERT_STOP ends them
 #endif
+#ifndef FOVPT_REINSERT_VISITS
+#define FOVPT_REINSERT_VISITS 2048
+#endif
 #ifndef FOVPT_REINSERT_STOP
 #define FOVPT_REINSERT_STOP 0.0015f
 #endif
@@ -351,7 +354,11 @@ __global__ void k_reinsert_find(TreeView T, int root, Move* __restrict__ moves, 
     int path_child = c, pivot = p, level = 0;
     int st_node[FOVPT_REINSERT_STACK];
     float st_inc[FOVPT_REINSERT_STACK];
-    while (pivot >= 0) {
+    // The bound prunes nothing among coincident boxes (merging costs no area there), and a search that opened every node below every
+    // level of its path would be quadratic in a scene of duplicates: a node's search ends after FOVPT_REINSERT_VISITS opened nodes
+    // and keeps the best position found so far (a normal search opens a few dozen).
+    int visits = FOVPT_REINSERT_VISITS;
+    while (pivot >= 0 && visits > 0) {
         const int l = T.left[pivot], r = T.right[pivot];
         const int sib = l == path_child ? r : l;
         const Box bs = T.box(sib);
@@ -361,10 +368,11 @@ __global__ void k_reinsert_find(TreeView T, int root, Move* __restrict__ moves, 
             const float m = merged_area(bin, bs);
             if (level > 0) { const float g = G - m; if (g > mv.gain) { mv.gain = g; mv.out = sib; mv.pivot = pivot; } }      // (level 0: beside its own sibling = where it is)
             if (sib >= 0) { const float inc = m - box_area(bs); if (G - inc - a_in > mv.gain) { st_node[0] = sib; st_inc[0] = inc; sp = 1; } }
-            while (sp > 0) {
+            while (sp > 0 && visits > 0) {
                 const int y = st_node[--sp];
                 const float inc = st_inc[sp];
                 if (!(G - inc - a_in > mv.gain)) continue;               // (the bound may have tightened since the push)
+                visits--;
                 const int ch[2] = {T.left[y], T.right[y]};
                 float mc[2], ic[2];
                 for (int k = 0; k < 2; k++) {

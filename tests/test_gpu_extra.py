@@ -729,6 +729,8 @@ def test_degenerate_geometry_builds_a_shallow_hierarchy(oracle):
     size, cfg = (96, 64), cfg_uniform(1, max_depth=2)
     r = make_gpu(model, scenes.ambient_probe(32, 16, 1.0), cam, size, cfg)
     assert 0 < r.stats().bvh_max_depth <= 21
+    # (the reinsertion search cannot prune among coincident boxes: its per-node visit budget keeps the build from going quadratic)
+    assert r.stats().ms_bvh_build < 3000.0, r.stats().ms_bvh_build
     r.render()
     S, F = make_oracle(oracle, model, scenes.ambient_probe(32, 16, 1.0), cam, size)
     oracle.render(S, F, cfg)
