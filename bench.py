@@ -548,7 +548,8 @@ def main():
                        "its slowest quad, 16 % box test + rank, 8 % LDS push / pop, 14 % loop; a closest-hit launch is three one-wave "
                        "workgroups per wave slot, started by the dispatcher as slots fall free, and lasts (waves per slot) x (a wave's "
                        "life) / (share of the launch the slots are busy)",
-            "source": "IMPORTED from profiles/r03_step_model.json (step anatomy, steps per wave, busy share: diagnostic builds); "
+            "source": "IMPORTED from profiles/r03_step_model.json (step anatomy, steps per wave, busy share: diagnostic builds of ROUND 3's "
+                      "kernels -- the step anatomy still holds, the steps per wave are 12-40 % fewer since round 4's reinsertion and vote); "
                       "measured_ms_per_frame_serialised from this run",
         }
     except Exception as e:                                      # the line is still valid without the model
@@ -568,8 +569,8 @@ def main():
                       "cycles per wave-level load, two per node step; a third costs +19 %, one fewer returns nothing) and is paced by its "
                       "dependent chain (load -> box test -> stack -> pop -> load) at the hardware's 8 waves per SIMD -- closest-hit time = "
                       "0.32 + 1.53 / (waves per SIMD) ms per frame -- with the vector ALUs about half busy (`valu`: half-empty waves, 16 "
-                      "rays in lockstep).  DESIGN.md section 4 has the occupancy sweep and the three probes; `achieved`/`peak`/`frac` are the "
-                      "contract's algorithmic-bytes figure against the 8 TB/s HBM roof",
+                      "rays in lockstep, since round 4 with a vote on when a node phase ends).  DESIGN.md section 4 and EXPERIMENTS.md (round 3) have the "
+                      "occupancy sweep and the three probes; `achieved`/`peak`/`frac` are the contract's algorithmic-bytes figure against the 8 TB/s HBM roof",
         # the contract's figure, for the configuration `value` is timed in: algorithmic bytes per launch / the launch's
         # HIP-event duration as the timed region runs (frames_in_flight as in `config`)
         "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
