@@ -22,6 +22,13 @@
 #define FOVPT_V_VOTE_ANYHIT 1      // occlusion rays end their node phases by the same vote as closest-hit rays (wavefront.hip, vote_leaf); 0: when
                                    // every ray of the wave has reached a leaf, as rounds 1-3 (A/B: street occlusion launches 0.755 -> 0.600 ms, atrium 0.250 -> 0.244)
 #endif
+#ifndef FOVPT_V_MIXED
+#define FOVPT_V_MIXED 1            // the pass after a vote is a MIXED step (leaf lanes test triangles, node lanes step, behind one wait: wavefront.hip
+                                   // mixed_step); 0: a leaf step in which the node lanes idle (A/B: atrium 0.667 -> 0.663, street 1.444 -> 1.409 with both on)
+#endif
+#ifndef FOVPT_V_MIXED_ANYHIT
+#define FOVPT_V_MIXED_ANYHIT 1     // the same for occlusion rays
+#endif
 #ifndef FOVPT_V_ANYHIT_SORT
 #define FOVPT_V_ANYHIT_SORT 0      // 1: occlusion rays visit a node's children nearest first, like closest-hit rays (A/B; the product uses storage order)
 #endif

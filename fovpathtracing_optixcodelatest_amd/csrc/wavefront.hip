@@ -829,12 +829,19 @@ __device__ inline void cyc_hist(uint32_t* h, uint32_t bin) { if (FOVPT_V_CYCLES 
 __shared__ float4 s_top[FOVPT_TOPN * 8];
 #endif
 
+template <bool ANY_HIT>
+__device__ inline void node_finish(const RayT& r, const QuadLane& q, QuadTrav& T, const float4& a, const float4& b CYC_P
+#if FOVPT_V_CYCLES
+                                   , uint32_t c0, uint32_t c1
+#endif
+);
+
 // wide internal node: lane j owns child j
 template <bool ANY_HIT, bool TOP = false>
 __device__ inline void node_step(const SceneView& sc, const RayT& r, const QuadLane& q, QuadTrav& T CYC_P)
 {
 #if FOVPT_V_CYCLES
-    uint32_t c0 = 0, c1 = 0, c2 = 0;
+    uint32_t c0 = 0, c1 = 0;
     if (C.on) c0 = cyc_stamp(T.cur);
 #endif
     // uniform base + 32-bit offset (fovpt_set_scene keeps nodes and triangles below 4 GB)
@@ -851,6 +858,24 @@ __device__ inline void node_step(const SceneView& sc, const RayT& r, const QuadL
     } else { a = np[0]; b = np[1]; }
 #else
     const float4 a = np[0], b = np[1];
+#endif
+    node_finish<ANY_HIT>(r, q, T, a, b CYC_A
+#if FOVPT_V_CYCLES
+                         , c0, c1
+#endif
+    );
+}
+
+// ... the rest of a node step, once the lane's child record (a, b) is there: box test, rank, push, pop
+template <bool ANY_HIT>
+__device__ inline void node_finish(const RayT& r, const QuadLane& q, QuadTrav& T, const float4& a, const float4& b CYC_P
+#if FOVPT_V_CYCLES
+                                   , uint32_t c0, uint32_t c1
+#endif
+)
+{
+#if FOVPT_V_CYCLES
+    uint32_t c2 = 0;
 #endif
     const int code = __float_as_int(b.z);
     float t;
@@ -896,6 +921,13 @@ __device__ inline void node_step(const SceneView& sc, const RayT& r, const QuadL
 #endif
 }
 
+template <bool ANY_HIT>
+__device__ inline bool leaf_finish(const RayT& r, const QuadLane& q, QuadTrav& T, const TriRec& R, uint32_t tri16 CYC_P
+#if FOVPT_V_CYCLES
+                                   , uint32_t c0, uint32_t c1
+#endif
+);
+
 // leaf: lane j owns triangle j (branch-free: the four lanes of 16 rays never agree on an early out).
 // A lane beyond the leaf's count repeats triangle 0: the duplicate candidate changes nothing.
 // Any-hit: returns true when a front-facing triangle was hit (the ray is occluded, nothing is popped).
@@ -918,6 +950,21 @@ __device__ inline bool leaf_step(const SceneView& sc, const RayT& r, const QuadL
     const TriRec R = load_tri_off(sc.tris, tri16 << 4);
 #define CYC_LEAF_END(x)
 #endif
+    return leaf_finish<ANY_HIT>(r, q, T, R, tri16 CYC_A
+#if FOVPT_V_CYCLES
+                                , c0, c1
+#endif
+    );
+}
+
+// ... the rest of a leaf step, once the lane's triangle record is there: Moeller-Trumbore, merge, pop
+template <bool ANY_HIT>
+__device__ inline bool leaf_finish(const RayT& r, const QuadLane& q, QuadTrav& T, const TriRec& R, uint32_t tri16 CYC_P
+#if FOVPT_V_CYCLES
+                                   , uint32_t c0, uint32_t c1
+#endif
+)
+{
     const V3 d = v3(r.dx, r.dy, r.dz);
     const V3 e1 = v3(R.e1x, R.e1y, R.e1z), e2 = v3(R.e2x, R.e2y, R.e2z);
     const V3 p = cross(d, e2);
@@ -948,6 +995,44 @@ __device__ inline bool leaf_step(const SceneView& sc, const RayT& r, const QuadL
     T.cur = *(const LdsInt*)T.top;
     CYC_LEAF_END(T.cur);
     return false;
+}
+
+// A MIXED step (round 4): the pass the wave makes when its vote ends a node phase.  The rays waiting at a leaf test their
+// triangles -- and the rays still at a node step theirs in the same pass, behind the SAME wait for memory: nodes and triangles
+// live in one allocation, so every live lane fetches 48 bytes from one base register (a node lane's third 16 bytes are not
+// used), then the node lanes and the leaf lanes finish their step one after the other.  The instructions are the ones two
+// separate passes would issue; what goes is one memory round trip and the idling of the node lanes through a leaf step.
+// Any-hit: returns true for a quad whose leaf step found an occluder.
+template <bool ANY_HIT>
+__device__ inline bool mixed_step(const SceneView& sc, const RayT& r, const QuadLane& q, QuadTrav& T, unsigned long long* diag)
+{
+    const bool at_node = T.cur >= 0;
+    const uint32_t lcode = (uint32_t)~T.cur;
+    const uint32_t tri16 = (lcode >> 3) + (q.j <= (lcode & 7u) ? q.j3 : 0u);
+    const uint32_t off = at_node ? (((uint32_t)T.cur << 7) | q.j32) : sc.tri_off + (tri16 << 4);
+    const float4* p = (const float4*)((const char*)sc.nodes + off);
+    const float4 x0 = p[0], x1 = p[1], x2 = p[2];
+    if (at_node) {
+        STEPSTAT(diag);
+#if FOVPT_V_CYCLES
+        Cyc Cdummy; Cdummy.init(false);
+        node_finish<ANY_HIT>(r, q, T, x0, x1, Cdummy, 0u, 0u);
+#else
+        node_finish<ANY_HIT>(r, q, T, x0, x1);
+#endif
+        return false;
+    }
+    STEPSTAT(diag + 2);
+    TriRec R;
+    R.v0x = x0.x; R.v0y = x0.y; R.v0z = x0.z; R.e1x = x0.w;
+    R.e1y = x1.x; R.e1z = x1.y; R.e2x = x1.z; R.e2y = x1.w;
+    R.e2z = x2.x; R.prim = __float_as_uint(x2.y); R.mesh = __float_as_uint(x2.z); R.pad = 0;
+#if FOVPT_V_CYCLES
+    Cyc Cdummy; Cdummy.init(false);
+    return leaf_finish<ANY_HIT>(r, q, T, R, tri16, Cdummy, 0u, 0u);
+#else
+    return leaf_finish<ANY_HIT>(r, q, T, R, tri16);
+#endif
 }
 
 // closest: store the hit record of the quad's ray AT THE RAY'S QUEUE POSITION (the shading kernel reads ray and
@@ -1054,7 +1139,16 @@ __device__ inline void traverse_quad(const SceneView& sc, const RayT& r, int* __
             const uint32_t nn = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(T.cur >= 0));   // of the lanes that stepped: who goes on
             if (vote_leaf(na, nn)) break;                                                                  // (wave-uniform)
         }
+#if FOVPT_V_MIXED
+        if (T.cur != TRAV_DONE) {
+#if FOVPT_V_STEPSTAT
+            if (T.cur >= 0) my_nodes++; else my_leaves++;
+#endif
+            mixed_step<false>(sc, r, q, T, diag);
+        }
+#else
         if (T.cur < 0 && T.cur != TRAV_DONE) { STEPSTAT(diag + 2); leaf_step<false>(sc, r, q, T CYC_A); RAYSTAT(my_leaves); }
+#endif
     }
 #if FOVPT_V_STEPSTAT
     T.steps = min(my_nodes, 4095u) | (min(my_leaves, 255u) << 12) | (min(T.n0, 63u) << 20);
@@ -1116,14 +1210,23 @@ __device__ inline void traverse_shadow_pool(const SceneView& sc, const PathState
             const uint32_t nn = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(T.cur >= 0));
             if (vote_leaf_anyhit(na, nn)) break;
         }
-        if (T.cur < 0 && T.cur != TRAV_DONE) {
-#else
-        while (T.cur >= 0) { STEPSTAT(diag); node_step<true>(sc, r, q, T CYC_A); }
+#if FOVPT_V_MIXED_ANYHIT
         if (T.cur != TRAV_DONE) {
-#endif
+            if (mixed_step<true>(sc, r, q, T, diag)) { occluded = true; T.cur = TRAV_DONE; }
+        }
+#else
+        if (T.cur < 0 && T.cur != TRAV_DONE) {
             STEPSTAT(diag + 2);
             if (leaf_step<true>(sc, r, q, T CYC_A)) { occluded = true; T.cur = TRAV_DONE; }
         }
+#endif
+#else
+        while (T.cur >= 0) { STEPSTAT(diag); node_step<true>(sc, r, q, T CYC_A); }
+        if (T.cur != TRAV_DONE) {
+            STEPSTAT(diag + 2);
+            if (leaf_step<true>(sc, r, q, T CYC_A)) { occluded = true; T.cur = TRAV_DONE; }
+        }
+#endif
     }
 }
 
