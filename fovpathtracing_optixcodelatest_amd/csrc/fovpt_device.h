@@ -15,9 +15,6 @@
 #ifndef FOVPT_V_CYCLES
 #define FOVPT_V_CYCLES 0           // 1: diagnostic build with s_memtime stamps inside the traversal steps (tools/stepcycles.py)
 #endif
-#ifndef FOVPT_V_PRUNE_NODE
-#define FOVPT_V_PRUNE_NODE 0       // 1: the pruning closest-hit build checks EVERY pop against the limit, not only those of a leaf step (A/B)
-#endif
 #ifndef FOVPT_V_VOTE_ANYHIT
 #define FOVPT_V_VOTE_ANYHIT 1      // occlusion rays end their node phases by the same vote as closest-hit rays (wavefront.hip, vote_leaf); 0: when
                                    // every ray of the wave has reached a leaf, as rounds 1-3 (A/B: street occlusion launches 0.755 -> 0.600 ms, atrium 0.250 -> 0.244)
