@@ -74,6 +74,9 @@ struct StateSet {
 #define FOVPT_LANES_DEFAULT 2
 #endif
 #define FOVPT_MAX_LANES 4
+#ifndef FOVPT_SETS_SLOT_LIMIT
+#define FOVPT_SETS_SLOT_LIMIT (16ull << 20)    // (~330 B of state and queues per slot and set)
+#endif
 
 struct fovpt_ctx {
     int device = 0;
@@ -115,11 +118,16 @@ struct fovpt_ctx {
     ncclComm_t comm = nullptr;
     int comm_rank = 0, comm_world = 0;
     DevBuf comm_packed, comm_gathered;
-    // Wavefront state, TWO sets used alternately by consecutive jobs: the tail of job k (its last occlusion
-    // rays and its resolve, on the shadow stream) runs beside the head of job k+1 (generate, camera rays)
-    StateSet set[FOVPT_MAX_LANES < 2 ? 2 : FOVPT_MAX_LANES];
-    unsigned nsets = 2;                    // = max(2, lanes)
-    unsigned jobs = 0;                     // jobs issued so far; job j uses set[j & 1]
+    // Wavefront state, several sets used in rotation by consecutive jobs: the tail of job k (its last occlusion
+    // rays and its resolve, on the shadow stream) runs beside the head of job k+1 (generate, camera rays).
+    // Round 4: TWICE as many sets as lanes, so that the job which follows job k on the same lane (job k + lanes) does not
+    // wait for job k's resolve before it may overwrite the path state: its main chain starts as soon as job k's has ended,
+    // and k's tail runs beside it.  (What a 1/N shard of a frame needs: its launches are short, and last occlusion launch +
+    // resolve were a third of a lane's cycle.)
+    StateSet set[2 * FOVPT_MAX_LANES];
+    unsigned nsets = 4;                    // sets in rotation for ordinary jobs = 2 * lanes (FOVPT_SETS: 2 .. 2 * FOVPT_MAX_LANES)
+    unsigned last_set = 0;                 // the set the most recent job used
+    unsigned jobs = 0;                     // jobs issued so far; job j runs on lane j % lanes
     int grid = 2048, grid_trace = 2048, grid_shadow = 1024, grid_shade = 1024;
     int async_last_shade = FOVPT_ASYNC_LAST_SHADE_DEFAULT;   // 1: the last shading launch of a job runs on the shadow stream (see run_job)
     uint64_t slot_budget = 64ull << 20;    // sample slots per wavefront job (~330 B of state and queues each, two sets)
@@ -396,9 +404,13 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     fd.tile_w = c->cfg.tile_w > 0 ? c->cfg.tile_w : 8; fd.tile_h = c->cfg.tile_h > 0 ? c->cfg.tile_h : 4;
 
     if (slots == 0) return FOVPT_OK;
-    StateSet& S = c->set[c->jobs % c->nsets];
-    // lane = set, except for the chunk jobs of an oversized launch: their memsets / snapshot copies are ordered on
-    // shadow_stream, so they all run on lane 0 (as before round 3)
+    // the chunk jobs of an oversized launch all run on lane 0 (their memsets / snapshot copies are ordered on shadow_stream,
+    // as before round 3) and, like every job of more than FOVPT_SETS_SLOT_LIMIT sample slots (~330 B of state each), rotate
+    // through no more sets than before round 4
+    const unsigned few = c->lanes < 2 ? 2u : (unsigned)c->lanes;
+    const unsigned nrot = (chunked || (unsigned long long)slots > FOVPT_SETS_SLOT_LIMIT || c->nsets < few) ? few : c->nsets;
+    const unsigned set_index = c->jobs == 0 ? 0u : (c->last_set + 1u) % nrot;
+    StateSet& S = c->set[set_index];
     const int fif = c->cfg.frames_in_flight > 0 ? c->cfg.frames_in_flight : c->lanes;
     const unsigned lanes = (unsigned)(fif < c->lanes ? fif : c->lanes);
     // chains_per_frame = 2: the job is TWO chains -- the halves of its sample slots, each with four of the eight queue shards, on
@@ -413,7 +425,15 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     if (S.used && two_chains) HIPCHK(c, hipStreamWaitEvent(c->lane_main[1], S.ev_done, 0));
     int rc = ensure_state(c, S, (size_t)slots, (size_t)launches, st);
     if (rc) return rc;
+    // the other sets of the rotation now rather than one per job: an allocation waits for the device, and the first jobs of a
+    // caller that keeps several frames in flight would each stop for one
+    for (unsigned k = 0; k < nrot && !chunked; k++)
+        if (k != set_index && (c->set[k].s_thr.bytes < (size_t)slots * 16 || c->set[k].s_rad.bytes < (size_t)slots * 16 * (size_t)c->cfg.max_depth)) {
+            rc = ensure_state(c, c->set[k], (size_t)slots, (size_t)launches, st);
+            if (rc) return rc;
+        }
     c->jobs++;
+    c->last_set = set_index;
     S.used = true;
 
     PathState ps;
@@ -609,7 +629,8 @@ int fovpt_create(fovpt_ctx** out, int device)
     if (const char* l = getenv("FOVPT_LANES")) { const int v = atoi(l); if (v >= 1 && v <= FOVPT_MAX_LANES) c->lanes = v; }
     if (const char* l = getenv("FOVPT_PARTITION")) { const int v = atoi(l); if (v >= 0 && v <= 2) c->partition = v; }
     if (const char* l = getenv("FOVPT_CHAINS")) { const int v = atoi(l); if (v == 1 || v == 2) c->chains_default = v; }
-    c->nsets = c->lanes < 2 ? 2u : (unsigned)c->lanes;
+    c->nsets = 2u * (unsigned)c->lanes;
+    if (const char* l = getenv("FOVPT_SETS")) { const int v = atoi(l); if (v >= 2 && v <= 2 * FOVPT_MAX_LANES) c->nsets = (unsigned)v; }
     c->lane_main[0] = c->stream; c->lane_shadow[0] = c->shadow_stream;
     for (int l = 1; l < c->lanes; l++) {
         if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->lane_main[l], hipStreamDefault, prio_hi);
@@ -1272,7 +1293,7 @@ int fovpt_debug_buffer(fovpt_ctx* c, const char* name, void** ptr, size_t* bytes
 {
     if (!c || !name || !ptr || !bytes) return FOVPT_E_INVALID;
     if (strcmp(name, "bvh_nodes") == 0 && c->has_scene) { *ptr = c->nodes; *bytes = (size_t)c->stats.bvh_bytes; return FOVPT_OK; }   // tools/bvhstat.py
-    StateSet& S = c->set[(c->jobs + 1u) & 1u];            // the set the most recent job used
+    StateSet& S = c->set[c->last_set];                    // the set the most recent job used
     struct { const char* n; DevBuf* b; } tab[] = {
         {"sq_o", &S.sq_o[0]}, {"sq_d", &S.sq_d[0]}, {"sq_vis", &S.sq_vis[0]}, {"sq_occ", &S.sq_occ[0]}, {"counters", &S.counters},
         {"hit", &S.s_hit}, {"trace", &S.s_trace}, {"queue_a_o", &S.q_o[0]}, {"queue_a_d", &S.q_d[0]}, {"queue_b_o", &S.q_o[1]}, {"queue_b_d", &S.q_d[1]},
@@ -1292,7 +1313,7 @@ int fovpt_debug_trace(fovpt_ctx* c, int n, const float* origins3, const float* d
     if (n == 0) return FOVPT_OK;
     HIPCHK(c, hipSetDevice(c->device));
     { const int rc_ = sync_all(c); if (rc_) return rc_; }
-    StateSet& S = c->set[c->jobs % c->nsets];
+    StateSet& S = c->set[(c->last_set + 1u) % 2u];                  // (the device is idle: any set will do)
     const size_t slots = (size_t)n * FOVPT_SHARDS;                  // all rays go to shard 0: its capacity must hold them
     int rc = ensure_state(c, S, slots, 1, c->stream);
     if (rc) return rc;

@@ -179,16 +179,24 @@ def test_frames_in_flight_do_not_change_the_frames(accumulate):
     out as with one -- resolves in issue order (progressive accumulation
     makes frame k depend on frame k-1), and work the caller queues on fovpt_stream() between two frames ordered between them
     (each frame is copied out and the ONE frame buffer cleared right behind it, six frames back to back, no host sync)."""
+    import os
     import torch
     size = (320, 180)
-    n = 6
+    n = 10                                                                           # (every state set of the rotation is used again)
     got = {}
-    for fif in (1, 2, 0):
+    for fif in (1, 2, 0, 23):
         cfg = cfg_foveated(24, 80, (1, 2, 4))
         cfg.accumulate = accumulate
-        cfg.frames_in_flight = fif if fif > 0 else 1
+        cfg.frames_in_flight = 2 if fif == 23 else fif if fif > 0 else 1
         cfg.chains_per_frame = 2 if fif == 0 else 1                                  # "0": one frame at a time, as two chains
-        r = make_gpu(scenes.atrium(9000), scenes.sky_probe(), scenes.ATRIUM_CAMERA, size, cfg, gaze=(200, 70))
+        # "23": two frames in flight over THREE state sets instead of the default four (round 4: a lane's next job no longer waits for
+        # the resolve of its previous one; FOVPT_SETS is read when the context is created)
+        if fif == 23:
+            os.environ["FOVPT_SETS"] = "3"
+        try:
+            r = make_gpu(scenes.atrium(9000), scenes.sky_probe(), scenes.ATRIUM_CAMERA, size, cfg, gaze=(200, 70))
+        finally:
+            os.environ.pop("FOVPT_SETS", None)
         frame = torch.zeros(size[0] * size[1], dtype=torch.int32, device="cuda")
         ext = torch.cuda.ExternalStream(r.stream)
         copies = []
@@ -205,7 +213,7 @@ def test_frames_in_flight_do_not_change_the_frames(accumulate):
         ext.synchronize()
         got[fif] = ([c.cpu() for c in copies], r.downloadAccum().copy())
         r.close()
-    for other in (2, 0):
+    for other in (2, 0, 23):
         for a, b in zip(got[1][0], got[other][0]):
             assert torch.equal(a, b) and int((a != 0).sum()) > 0.9 * a.numel()
         assert _eq(got[1][1], got[other][1])

@@ -17,7 +17,7 @@ cfg.spp_periphery, cfg.spp_middle, cfg.spp_fovea = 1, 2, 8
 cfg.rank, cfg.world = 0, $N
 r.config = cfg
 r.launchParams.frame.c.x, r.launchParams.frame.c.y = W // 2, H // 2
-for _ in range(8):
+for _ in range(${FRAMES:-8}):
     r.launchParams.frame.subframe_index = 0; r.render_async()
 r.synchronize()
 PY
@@ -29,7 +29,7 @@ import csv,re
 rows=list(csv.DictReader(open("$OUT/s_kernel_trace.csv")))
 rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 idx=[i for i,r in enumerate(rows) if "k_generate" in r["Kernel_Name"]]
-i0=idx[-3]; i1=idx[-2]
+i0=idx[-2-${SPAN:-1}]; i1=idx[-2]
 t0=int(rows[i0]["Start_Timestamp"])
 for r in rows[i0:i1+1]:
     m=re.search(r"(k_[a-z_]+)",r["Kernel_Name"])
