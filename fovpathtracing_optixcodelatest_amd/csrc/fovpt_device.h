@@ -26,6 +26,9 @@
 #ifndef FOVPT_V_MIXED_ANYHIT
 #define FOVPT_V_MIXED_ANYHIT 1     // the same for occlusion rays
 #endif
+#ifndef FOVPT_V_GEN_OWNED
+#define FOVPT_V_GEN_OWNED 1         // a rank of a tile-sharded frame generates over its own tiles only (k_generate<true>)
+#endif
 #ifndef FOVPT_V_ANYHIT_SORT
 #define FOVPT_V_ANYHIT_SORT 0      // 1: occlusion rays visit a node's children nearest first, like closest-hit rays (A/B; the product uses storage order)
 #endif

@@ -599,6 +599,77 @@ __device__ inline bool ring_alive(const FrameDev& fd, const PassDev& P, uint32_t
 }
 
 // ---- generate ----------------------------------------------------------------------------
+// A rank's share of pass P in the tile-sharded frame, as an index space of its own: tile rows x the rank's tiles of a row
+// (every world-th tile, launch_owned) x the tile's launch indices x samples.  k_generate<true> walks it instead of all sample
+// slots -- 1 / world of the work; the sample slot of a launch index, and so everything downstream, is the same.
+struct OwnedSpace {
+    uint32_t ty0, tile_rows, per_row, tile_lis, count;      // first tile row, tile rows, the rank's tiles per tile row (at most), launch indices per tile
+    __host__ __device__ inline void init(const FrameDev& fd, const PassDev& P)
+    {
+        const uint32_t tw = (uint32_t)fd.tile_w, th = (uint32_t)fd.tile_h, tiles_x = (P.gw + tw - 1u) / tw;
+        ty0 = P.row0 / th;
+        tile_rows = P.row1 > P.row0 ? (P.row1 - 1u) / th - ty0 + 1u : 0u;
+        per_row = (tiles_x + (uint32_t)fd.world - 1u) / (uint32_t)fd.world;
+        tile_lis = tw * th;
+        count = tile_rows * per_row * tile_lis * P.spp;
+    }
+    // entry v -> launch index (lx, ly) and sample s; false: the entry is padding (a tile beyond the row's end, a launch index
+    // beyond the grid or outside the job's rows)
+    __device__ inline bool at(const FrameDev& fd, const PassDev& P, uint32_t v, uint32_t& lx, uint32_t& ly, uint32_t& s) const
+    {
+        const uint32_t tw = (uint32_t)fd.tile_w, th = (uint32_t)fd.tile_h, world = (uint32_t)fd.world;
+        const uint32_t t = v / P.spp;
+        s = v - t * P.spp;
+        const uint32_t tile = t / tile_lis, in = t - tile * tile_lis;
+        const uint32_t row = tile / per_row, k = tile - row * per_row;
+        const uint32_t ty = ty0 + row;
+        const uint32_t first = ((uint32_t)fd.rank + world - (3u * ty + P.frame_pass) % world) % world;    // (tx + 3 ty + pass) % world == rank
+        const uint32_t tx = first + k * world;
+        const uint32_t iy = in / tw;
+        lx = tx * tw + (in - iy * tw);
+        ly = ty * th + iy;
+        return lx < P.gw && ly >= P.row0 && ly < P.row1;
+    }
+};
+
+// One block iteration of the generate kernels: the camera rays of its live threads (launch index (lx, ly) of pass P, sample s,
+// sample slot `slot`, pixel (ix, iy) from ring_alive) and their append to queue 0.  Called by every thread of the block.
+__device__ inline void generate_rays(const FrameDev& fd, const PathState& ps, const RayQueue& queue0, uint32_t cap, Counters* __restrict__ cnt,
+                                     uint32_t* s_scratch, uint32_t sel, const PassDev& P, bool live, uint32_t slot, uint32_t lx, uint32_t ly,
+                                     uint32_t s, uint32_t ix, uint32_t iy)
+{
+    V3 ray_dir = v3(0.f);
+    if (live) {
+        uint32_t seed = tea4(ly * (uint32_t)fd.w + lx, P.subframe);        // :411
+        for (uint32_t k = 0; k < s; k++) { (void)rnd(seed); (void)rnd(seed); }   // earlier samples' jitter draws
+        Rng rng;                                                            // Random(seed), maths.h:176-180
+        rng.s1 = 315645664u + seed;
+        rng.s2 = rng.s1 ^ 0x13ab45feu;
+        const float jx = rnd(seed);                                         // :479, x first
+        const float jy = rnd(seed);
+        const float dx = 2.0f * (((float)ix + jx) / (float)fd.w) - 1.0f;    // :483-486
+        const float dy = 2.0f * (((float)iy + jy) / (float)fd.h) - 1.0f;
+        const V3 U = v3(fd.U[0], fd.U[1], fd.U[2]), V = v3(fd.V[0], fd.V[1], fd.V[2]), W = v3(fd.W[0], fd.W[1], fd.W[2]);
+        const V3 dir = normalize(dx * U + dy * V + W);                      // :491
+        ray_dir = dir;
+        ps.rng[slot] = make_uint4(rng.s1, rng.s2, 0u, 0u);                  // stateFlags 0, depth 0
+        // Nothing else is initialised: pathThroughput / rayEta are (1,1,1) / 1 until the first shaded hit
+        // (k_shade), the radiance cells [0, depth) and alpha are written exactly once before resolve
+        // reads them (depth and FLAG_ALPHA_SET tell it which), :450-451
+        if (ps.guide_n) { ps.guide_n[slot] = make_float4(0.f, 0.f, 0.f, 0.f); ps.guide_a[slot] = make_float4(0.f, 0.f, 0.f, 0.f); }
+        if (s == P.spp - 1) {                                               // backplate of the last sample, :495
+            float u, v;
+            probe_dir_to_uv(dir, u, v);
+            ps.backplate[P.launch_base + (ly - P.row0) * P.gw + lx] = probe_eval(fd.probe, fd.probe_row_mul, u, v);
+        }
+    }
+    const uint32_t pos = block_append(cnt, FOVPT_CNT_Q(0), cap, live, s_scratch, sel);
+    if (live) {
+        queue0.o[pos] = make_float4(fd.eye[0], fd.eye[1], fd.eye[2], __uint_as_float(slot));
+        queue0.d[pos] = f4(ray_dir, 0.f);
+    }
+}
+
 __global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, PathState ps, RayQueue queue0, uint32_t cap,
                                                           Counters* __restrict__ cnt, uint32_t slot_begin, uint32_t total_slots, uint32_t sel)
 {
@@ -609,7 +680,6 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, Pat
         bool live = slot < total_slots;
         int p = 0;
         uint32_t lx = 0, ly = 0, s = 0, ix = 0, iy = 0;
-        V3 ray_dir = v3(0.f);
         if (live) {
             while (p + 1 < fd.npass && slot >= fd.pass[p + 1].slot_base) p++;
             const PassDev& P = fd.pass[p];
@@ -621,36 +691,34 @@ __global__ __launch_bounds__(FOVPT_BLOCK) void k_generate(const FrameDev fd, Pat
             ly += P.row0;                                      // slots and launch records are relative to the chunk
             live = ring_alive(fd, P, lx, ly, ix, iy) && launch_owned(fd, p, lx, ly);
         }
-        if (live) {
-            const PassDev& P = fd.pass[p];
-            uint32_t seed = tea4(ly * (uint32_t)fd.w + lx, P.subframe);        // :411
-            for (uint32_t k = 0; k < s; k++) { (void)rnd(seed); (void)rnd(seed); }   // earlier samples' jitter draws
-            Rng rng;                                                            // Random(seed), maths.h:176-180
-            rng.s1 = 315645664u + seed;
-            rng.s2 = rng.s1 ^ 0x13ab45feu;
-            const float jx = rnd(seed);                                         // :479, x first
-            const float jy = rnd(seed);
-            const float dx = 2.0f * (((float)ix + jx) / (float)fd.w) - 1.0f;    // :483-486
-            const float dy = 2.0f * (((float)iy + jy) / (float)fd.h) - 1.0f;
-            const V3 U = v3(fd.U[0], fd.U[1], fd.U[2]), V = v3(fd.V[0], fd.V[1], fd.V[2]), W = v3(fd.W[0], fd.W[1], fd.W[2]);
-            const V3 dir = normalize(dx * U + dy * V + W);                      // :491
-            ray_dir = dir;
-            ps.rng[slot] = make_uint4(rng.s1, rng.s2, 0u, 0u);                  // stateFlags 0, depth 0
-            // Nothing else is initialised: pathThroughput / rayEta are (1,1,1) / 1 until the first shaded hit
-            // (k_shade), the radiance cells [0, depth) and alpha are written exactly once before resolve
-            // reads them (depth and FLAG_ALPHA_SET tell it which), :450-451
-            if (ps.guide_n) { ps.guide_n[slot] = make_float4(0.f, 0.f, 0.f, 0.f); ps.guide_a[slot] = make_float4(0.f, 0.f, 0.f, 0.f); }
-            if (s == P.spp - 1) {                                               // backplate of the last sample, :495
-                float u, v;
-                probe_dir_to_uv(dir, u, v);
-                ps.backplate[P.launch_base + (ly - P.row0) * P.gw + lx] = probe_eval(fd.probe, fd.probe_row_mul, u, v);
-            }
-        }
-        const uint32_t pos = block_append(cnt, FOVPT_CNT_Q(0), cap, live, s_scratch, sel);
-        if (live) {
-            queue0.o[pos] = make_float4(fd.eye[0], fd.eye[1], fd.eye[2], __uint_as_float(slot));
-            queue0.d[pos] = f4(ray_dir, 0.f);
-        }
+        generate_rays(fd, ps, queue0, cap, cnt, s_scratch, sel, fd.pass[p], live, slot, lx, ly, s, ix, iy);
+    }
+}
+
+// The same for a rank of a tile-sharded frame (world > 1, one chain): the grid walks the rank's own tiles, see OwnedSpace -- every
+// pass padded to whole block iterations, so that a block iteration serves ONE pass and reads its record with scalar loads.
+__global__ __launch_bounds__(FOVPT_BLOCK) void k_generate_owned(const FrameDev fd, PathState ps, RayQueue queue0, uint32_t cap,
+                                                                Counters* __restrict__ cnt)
+{
+    __shared__ uint32_t s_scratch[6];
+    static_assert(FOVPT_MAX_PASSES == 3, "the pass of a block iteration is selected by hand below");
+    OwnedSpace o0, o1, o2;
+    o0.count = o1.count = o2.count = 0u;
+    if (fd.npass > 0) o0.init(fd, fd.pass[0]);
+    if (fd.npass > 1) o1.init(fd, fd.pass[1]);
+    if (fd.npass > 2) o2.init(fd, fd.pass[2]);
+    const uint32_t b0 = (o0.count + FOVPT_BLOCK - 1u) / FOVPT_BLOCK, b1 = (o1.count + FOVPT_BLOCK - 1u) / FOVPT_BLOCK,
+                   b2 = (o2.count + FOVPT_BLOCK - 1u) / FOVPT_BLOCK;
+    for (uint32_t it = blockIdx.x; it < b0 + b1 + b2; it += gridDim.x) {
+        const int p = it < b0 ? 0 : it < b0 + b1 ? 1 : 2;
+        const OwnedSpace own = p == 0 ? o0 : p == 1 ? o1 : o2;
+        const PassDev& P = fd.pass[p];
+        const uint32_t v = (it - (p == 0 ? 0u : p == 1 ? b0 : b0 + b1)) * FOVPT_BLOCK + threadIdx.x;
+        uint32_t lx = 0, ly = 0, s = 0, ix = 0, iy = 0;
+        bool live = v < own.count && own.at(fd, P, v, lx, ly, s);
+        const uint32_t slot = P.slot_base + ((ly - P.row0) * P.gw + lx) * P.spp + s;
+        live = live && ring_alive(fd, P, lx, ly, ix, iy) && launch_owned(fd, p, lx, ly);
+        generate_rays(fd, ps, queue0, cap, cnt, s_scratch, 0u, P, live, slot, lx, ly, s, ix, iy);
     }
 }
 
@@ -2064,7 +2132,20 @@ __global__ void k_math(int op, const float* a, const float* b, float* out, size_
 void fovpt_launch_generate(hipStream_t st, const FrameDev& fd, PathState ps, RayQueue queue0, uint32_t cap, Counters* cnt, uint32_t slot_begin,
                            uint32_t slot_end, int grid, uint32_t sel)
 {
-    hipLaunchKernelGGL(k_generate, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, ps, queue0, cap, cnt, slot_begin, slot_end, sel);
+    // a rank of a tile-sharded frame walks its own tiles only (one chain: a half-frame chain is a range of sample slots).
+    // Its index space is padded (tiles beyond a row's end, launch indices beyond the grid's edge): a queue shard holds
+    // slots / 8 + 512 entries and receives every eighth block iteration, so the space must not be larger than the slots
+    // themselves -- it is not, except for grids a few launch indices wide, which go the other way.
+    unsigned long long space = 0;
+    for (int p = 0; p < fd.npass && p < FOVPT_MAX_PASSES; p++) {
+        OwnedSpace o;
+        o.init(fd, fd.pass[p]);
+        space += ((unsigned long long)o.tile_rows * o.per_row * o.tile_lis * fd.pass[p].spp + FOVPT_BLOCK - 1u) / FOVPT_BLOCK * FOVPT_BLOCK;   // (64-bit: o.count may have wrapped)
+    }
+    if (FOVPT_V_GEN_OWNED && fd.world > 1 && sel == 0u && slot_begin == 0u && slot_end == fd.total_slots && space <= (unsigned long long)fd.total_slots)
+        hipLaunchKernelGGL(k_generate_owned, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, ps, queue0, cap, cnt);
+    else
+        hipLaunchKernelGGL(k_generate, dim3(grid), dim3(FOVPT_BLOCK), 0, st, fd, ps, queue0, cap, cnt, slot_begin, slot_end, sel);
 }
 void fovpt_launch_traverse(hipStream_t st, SceneView sc, PathState ps, RayQueue queue, ShadowQueue sq, uint32_t cap,
                            Counters* cnt, int it_closest, int it_shadow, int grid, hipEvent_t done, uint32_t sel)
