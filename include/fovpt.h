@@ -171,7 +171,10 @@ typedef struct fovpt_config {
                                    about twice as long from first to last kernel); 3 and 4 are accepted and measured slower
                                    than 2 (a context has FOVPT_LANES = 2 stream pairs unless the environment says more; a
                                    larger value means all of them).  Results do not depend on it: resolves
-                                   run in issue order, and fovpt_stream() is ordered behind every finished frame.        */
+                                   run in issue order, and fovpt_stream() is ordered behind every finished frame.
+                                   (Path state and queues exist once per state set; jobs of up to 16 Mi sample slots rotate
+                                   through twice as many sets as stream pairs -- FOVPT_SETS -- so that a frame's head does
+                                   not wait for the resolve of the frame two before it.)                                 */
     int32_t chains_per_frame;   /* 0 / 1 = a frame is one chain of dependent launches; 2 = every frame is rendered as TWO
                                    independent chains over halves of its sample slots (each with four of the eight queue
                                    shards, on its own stream pair) and resolved once: for a caller that synchronises after
