@@ -129,6 +129,7 @@ struct fovpt_ctx {
     unsigned last_set = 0;                 // the set the most recent job used
     unsigned jobs = 0;                     // jobs issued so far; job j runs on lane j % lanes
     int grid = 2048, grid_trace = 2048, grid_shadow = 1024, grid_shade = 1024;
+    int spread_occlusion = 1;              // sharded frames: one occlusion launch of a first-lane job runs on the second lane's shadow stream (FOVPT_SPREAD_OCCLUSION)
     int async_last_shade = FOVPT_ASYNC_LAST_SHADE_DEFAULT;   // 1: the last shading launch of a job runs on the shadow stream (see run_job)
     uint64_t slot_budget = 64ull << 20;    // sample slots per wavefront job (~330 B of state and queues each, two sets)
     // stats
@@ -471,6 +472,18 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
     // async_last_shade it runs on the shadow stream, in front of the last occlusion launch and the resolve, so the main stream
     // is free for the next job's generate and camera rays one shading launch earlier.
     const bool tail_async = c->async_last_shade != 0;
+    // Sharded frames (world > 1): the completion stream -- the first lane's shadow stream -- carries every job's resolve (whose
+    // writer search and clearing cover the whole frame on every rank) on top of that lane's occlusion launches and is then as
+    // long as the main chains (kernel trace, round 4).  One occlusion launch of a first-lane job moves to the second lane's
+    // shadow stream: occlusion launches depend on their shading launch only, and the resolve waits for all of them.
+    int spread_it = (c->spread_occlusion && fd.world > 1 && lanes > 1u && lane == 0u && !two_chains && !chunked && !tail_async
+                           && c->cfg.max_depth >= 2) ? (c->spread_occlusion == 2 ? 1 : -2) : -1;      // -2: the job's LAST one (below)
+    // Which one: a launch is queued when the job is issued and holds the stream's later entries back until its own shading launch
+    // has run.  The job's last occlusion launch is the smallest and the resolve waits for it anyway -- but behind it the other
+    // lane's next job would find its occlusion launches held back for a whole chain, and with more bounces than shadow queue
+    // buffers (iters > FOVPT_NSQ) that job's main chain waits for them (measured: C5, depth 8, 1/8 shard 0.76 -> 1.0 ms).  So:
+    // the last launch when no main chain can depend on an occlusion launch, else the second (held back for one bounce only).
+    if (spread_it == -2) spread_it = iters <= nsq ? iters - 1 : 1;
     // One chain: the sample slots [slot_begin, slot_end) through the queue shards of `sel` (0: all eight; 1 / 2: one half), with
     // 1 / div of the usual grids.
     auto issue_chain = [&](hipStream_t st, hipStream_t ss, uint32_t sel, uint32_t slot_begin, uint32_t slot_end, int div,
@@ -493,6 +506,12 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
                 { Timed t(c, 2, st); fovpt_launch_shade(st, fd, sc, ps, qa, qb, sq[it % nsq], cap, cnt, it, g_shade, ev_shade[it], sel); }
                 HIPCHK(c, hipStreamWaitEvent(ss, ev_shade[it], 0));
             }
+            if (it == spread_it) {
+                // (a sharded frame on the first lane: this bounce's occlusion rays run on the OTHER lane's shadow stream -- the
+                // completion stream carries every job's resolve as well; the resolve below waits for it)
+                HIPCHK(c, hipStreamWaitEvent(c->lane_shadow[1], ev_shade[it], 0));
+                { Timed t(c, 3, c->lane_shadow[1]); fovpt_launch_traverse(c->lane_shadow[1], sc, ps, qb, sq[it % nsq], cap, cnt, -1, it, g_shadow, ev_shadow[it], sel); }
+            } else
             { Timed t(c, 3, ss); fovpt_launch_traverse(ss, sc, ps, qb, sq[it % nsq], cap, cnt, -1, it, g_shadow, ev_shadow[it], sel); }
             if (!last) { Timed t(c, 1, st); fovpt_launch_traverse(st, sc, ps, qb, sq[0], cap, cnt, it + 1, -1, g_trace, (tail_async && it + 2 == iters) ? ev_last_closest : nullptr, sel); }
             const RayQueue tmp = qa; qa = qb; qb = tmp;
@@ -513,6 +532,7 @@ int run_job(fovpt_ctx* c, const fovpt_launch_params* lp, const PassDev* passes_i
         // earlier one's), behind whatever the caller has queued on fovpt_stream() since the previous frame, and in front of what it
         // queues next.  A job of the second lane joins it behind its last occlusion launch (which waited for its last shade).
         if (ss != c->shadow_stream) HIPCHK(c, hipStreamWaitEvent(c->shadow_stream, S.ev_shadow[iters - 1], 0));
+        if (spread_it >= 0 && spread_it < iters) HIPCHK(c, hipStreamWaitEvent(c->shadow_stream, S.ev_shadow[spread_it], 0));
     }
     { Timed t(c, 4, c->shadow_stream); fovpt_launch_resolve(c->shadow_stream, fd, ps, cnt, S.ev_done); }
     HIPCHK(c, hipGetLastError());
@@ -628,6 +648,7 @@ int fovpt_create(fovpt_ctx** out, int device)
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->shadow_stream, hipStreamDefault, prio_lo);
     if (const char* l = getenv("FOVPT_LANES")) { const int v = atoi(l); if (v >= 1 && v <= FOVPT_MAX_LANES) c->lanes = v; }
     if (const char* l = getenv("FOVPT_PARTITION")) { const int v = atoi(l); if (v >= 0 && v <= 2) c->partition = v; }
+    if (const char* l = getenv("FOVPT_SPREAD_OCCLUSION")) c->spread_occlusion = atoi(l);      // 0 off, 1 the last occlusion launch, 2 the second (A/B)
     if (const char* l = getenv("FOVPT_CHAINS")) { const int v = atoi(l); if (v == 1 || v == 2) c->chains_default = v; }
     c->nsets = 2u * (unsigned)c->lanes;
     if (const char* l = getenv("FOVPT_SETS")) { const int v = atoi(l); if (v >= 2 && v <= 2 * FOVPT_MAX_LANES) c->nsets = (unsigned)v; }
