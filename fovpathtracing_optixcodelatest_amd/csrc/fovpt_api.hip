@@ -1097,12 +1097,19 @@ Rccl& rccl()
     static Rccl R;
     if (R.tried) return R;
     R.tried = true;
-    const char* names[] = {getenv("FOVPT_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    for (const char* n : names) {
+    // A copy the process already holds comes first (RTLD_NOLOAD): a host that has PyTorch loaded has PyTorch's bundled
+    // librccl.so -- another file than /opt/rocm's librccl.so.1, so asking for the latter by name would put a SECOND RCCL into the
+    // process (fovpathtracing_optixcodelatest_amd/lib.py loads torch's copy first when torch is installed and not imported yet).
+    const char* names[] = {getenv("FOVPT_RCCL_LIB"), "librccl.so", "librccl.so.1", "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (int k = 0; k < 6 && !R.lib; k++) {
+        const char* n = names[k];
         if (!n || !*n) continue;
-        R.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-        if (R.lib) break;
-        R.why = dlerror() ? dlerror() : "dlopen failed";
+        const bool only_if_loaded = k == 1 || k == 2;
+        // (RTLD_LOCAL: every entry point is looked up with dlsym, and RCCL brings librocm_smi64 with it, whose `amd::smi` globals
+        // must not become the process's: /opt/rocm's libamd_smi.so -- which PyTorch's device queries load -- defines the same ones,
+        // and two libraries then run their static destructors on one object)
+        R.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | (only_if_loaded ? RTLD_NOLOAD : 0));
+        if (!R.lib && !only_if_loaded) R.why = dlerror() ? dlerror() : "dlopen failed";
     }
     if (!R.lib) { if (R.why.empty()) R.why = "librccl not found"; return R; }
     struct { const char* n; void** f; } syms[] = {

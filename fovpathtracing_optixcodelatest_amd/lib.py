@@ -69,6 +69,32 @@ def _share_torch_hip_runtime():
             pass
 
 
+def share_torch_rccl():
+    """The same for RCCL, before the library's own transport (fovpt_comm_*) loads one: PyTorch bundles a librccl.so of its own
+    (another file than /opt/rocm's librccl.so.1) and the library takes whichever copy the process already holds: with torch
+    installed but not imported yet, torch's copy is loaded here, so that either order ends with one RCCL.  Loaded RTLD_LOCAL, as
+    the library loads it: RCCL brings librocm_smi64 along, whose `amd::smi` globals also exist in /opt/rocm's libamd_smi.so
+    (which torch's device queries load) -- made global, the two run their static destructors on one object and the process
+    aborts with a double free when it exits (round 4: this transport first, `import torch` afterwards).
+    FOVPT_SYSTEM_HIP=1 or FOVPT_RCCL_LIB skip this."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("FOVPT_SYSTEM_HIP") or os.environ.get("FOVPT_RCCL_LIB"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.submodule_search_locations:
+        return
+    rccl = os.path.join(list(spec.submodule_search_locations)[0], "lib", "librccl.so")
+    if os.path.exists(rccl):
+        try:
+            C.CDLL(rccl)
+        except OSError:
+            pass
+
+
 def load():
     global _lib
     if _lib is not None:

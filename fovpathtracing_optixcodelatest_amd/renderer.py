@@ -167,11 +167,13 @@ class SampleRenderer:
     # -- the RCCL transport of that gather inside the library (fovpt_comm_*, fovpt_gather_frame): what a C++ host uses
     @staticmethod
     def comm_unique_id():
+        lib.share_torch_rccl()
         buf = C.create_string_buffer(128)
         lib.check(None, lib.load().fovpt_comm_get_unique_id(buf))
         return buf.raw
 
     def comm_init(self, unique_id, rank, world):
+        lib.share_torch_rccl()
         self._check(self._L.fovpt_comm_init(self._ctx, C.c_char_p(unique_id), rank, world))
 
     def comm_destroy(self):
