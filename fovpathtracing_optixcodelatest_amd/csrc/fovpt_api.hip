@@ -131,7 +131,7 @@ struct fovpt_ctx {
     int grid = 2048, grid_trace = 2048, grid_shadow = 1024, grid_shade = 1024;
     int spread_occlusion = 1;              // sharded frames: one occlusion launch of a first-lane job runs on the second lane's shadow stream (FOVPT_SPREAD_OCCLUSION)
     int async_last_shade = FOVPT_ASYNC_LAST_SHADE_DEFAULT;   // 1: the last shading launch of a job runs on the shadow stream (see run_job)
-    uint64_t slot_budget = 64ull << 20;    // sample slots per wavefront job (~330 B of state and queues each, two sets)
+    uint64_t slot_budget = 64ull << 20;    // sample slots per wavefront job (~330 B of state and queues each and per set; jobs above FOVPT_SETS_SLOT_LIMIT rotate through one set per lane)
     // stats
     fovpt_stats stats;
     std::vector<EventPair> pending;
